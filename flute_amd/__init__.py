@@ -1,0 +1,11 @@
+"""flute_amd -- MI355X-native silent-OT correlation engine for FLUTE (host-side mirror).
+
+The compute path is libflute_sot.so (hand-written HIP for gfx950, C ABI in include/flute_sot.h).
+This package mirrors the reference's interface for the path (zappot silent_ot Sender/Receiver,
+gmw SilentMtProvider) on top of that ABI. There is no CPU fallback: without the library or a
+gfx950 device every compute call raises.
+"""
+from .lib import SotError, load_library, device_count  # noqa: F401
+from .silent_ot import (QuasiCyclicConf, Engine, Sender, Receiver, MultType,  # noqa: F401
+                        sample_base_choice_bits, fake_base)
+from .mul_triple import MulTriples, SilentMtProvider  # noqa: F401

@@ -1,0 +1,606 @@
+// GGM / PPRF expansion, tile transposes, CR hashes and MT-bit derivation for gfx950.
+//
+// Data layout in HBM
+//   interior GGM level l : [set][node 0..2^l)[tree%8] Blocks   (set = tree/8, the reference's [Block;8] nodes,
+//                          zappot/src/silent_ot/pprf.rs:126)
+//   leaves "V"           : V[128*(set + nsets*(leaf/16)) + 8*(leaf%16) + tree%8]  -- exactly the order in which
+//                          copy_out (pprf.rs:810-835) feeds 128-Block tiles to the bit transpose, so
+//                          rT[r][col] bit j == V[128*col + j] bit r. The QC stage consumes V directly.
+//   sums                 : [level][set][keep][tree%8] Blocks
+#include "aes_dev.h"
+#include "sot_internal.h"
+#include <string.h>
+
+#define GGM_BLOCK 256
+
+// ------------------------------------------------------------------------------------------------
+// roots: worker t = set % T owns AesRng(seed ^ t); its i-th group (i = set / T) takes keystream blocks
+// 8i..8i+7 (pprf.rs:115,128,135-137; util/aes_rng.rs:109-122)
+__global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t parts, blk_t *__restrict__ out) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= parts) return;
+    uint32_t set = tr >> 3, j = tr & 7;
+    uint32_t t = set % T, i = set / T;
+    blk_t ctr = make_uint4(8 * i + j, 0, 0, 0);
+    out[tr] = aes_encrypt(te, rks + 44 * t, ctr);
+}
+
+// generic-key CTR keystream: out[i] = AES_rk(LE128(first + i))   (util/aes_rng.rs:109-122)
+__global__ void k_aes_ctr(const uint32_t *__restrict__ rk, uint64_t first, blk_t *__restrict__ out, uint64_t n) {
+    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t srk[44];
+    aes_lds_fill(te);
+    if (threadIdx.x < 44) srk[threadIdx.x] = rk[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c = first + i;
+        out[i] = aes_encrypt(te, srk, make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0, 0));
+    }
+}
+
+// mode 0: ECB encrypt, mode 1: x ^ AES_kh(x)
+__global__ void k_aes_ecb(const uint32_t *__restrict__ rk, const blk_t *__restrict__ in, blk_t *__restrict__ out,
+                          uint64_t n, int mode) {
+    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t srk[44];
+    aes_lds_fill(te);
+    if (threadIdx.x < 44) srk[threadIdx.x] = mode ? c_rk_fixed[AES_KH][threadIdx.x] : rk[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        blk_t x = in[i];
+        blk_t e = aes_encrypt(te, srk, x);
+        out[i] = mode ? bxor(e, x) : e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one GGM level for every tree: child[2j+k] = AES_{k_k}(parent[j]) ^ parent[j], per-level XOR sums
+// (pprf.rs:141-194 sender, :388-450 receiver). blockIdx.y = set.
+template <bool LAST>
+__global__ void __launch_bounds__(GGM_BLOCK)
+    k_ggm_level(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t lvl, uint32_t nsets, uint64_t cols,
+                blk_t *__restrict__ sums /* this level: [set][2][8] */) {
+    __shared__ uint32_t te[4][256];
+    __shared__ blk_t red[GGM_BLOCK / 64][2][8];
+    aes_lds_fill(te);
+    const uint32_t set = blockIdx.y;
+    const uint64_t per_set = (uint64_t)8 << lvl;  // parent Blocks of this set
+    const blk_t *pin = in + (uint64_t)set * per_set;
+    blk_t acc0 = bzero(), acc1 = bzero();
+    for (uint64_t idx = (uint64_t)blockIdx.x * GGM_BLOCK + threadIdx.x; idx < per_set;
+         idx += (uint64_t)gridDim.x * GGM_BLOCK) {
+        blk_t p = pin[idx];
+        blk_t c0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], p), p);
+        blk_t c1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], p), p);
+        acc0 = bxor(acc0, c0);
+        acc1 = bxor(acc1, c1);
+        uint64_t node = idx >> 3;
+        uint32_t t8 = idx & 7;
+        if (!LAST) {
+            blk_t *pout = out + (uint64_t)set * per_set * 2;
+            pout[(2 * node) * 8 + t8] = c0;
+            pout[(2 * node + 1) * 8 + t8] = c1;
+        } else {
+            // leaves 2*node, 2*node+1 live in the same 16-leaf tile
+            uint64_t leaf = 2 * node;
+            uint64_t tile = set + (uint64_t)nsets * (leaf >> 4);
+            if (tile < cols) {
+                blk_t *pv = out + tile * 128 + 8 * (leaf & 15) + t8;
+                pv[0] = c0;
+                pv[8] = c1;
+            }
+        }
+    }
+    // XOR-reduce over lanes with equal tree%8 (lane bits 3..5), then over the block's waves
+    for (int off = 8; off < 64; off <<= 1) {
+        acc0.x ^= __shfl_xor(acc0.x, off);
+        acc0.y ^= __shfl_xor(acc0.y, off);
+        acc0.z ^= __shfl_xor(acc0.z, off);
+        acc0.w ^= __shfl_xor(acc0.w, off);
+        acc1.x ^= __shfl_xor(acc1.x, off);
+        acc1.y ^= __shfl_xor(acc1.y, off);
+        acc1.z ^= __shfl_xor(acc1.z, off);
+        acc1.w ^= __shfl_xor(acc1.w, off);
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
+        red[wave][0][lane] = acc0;
+        red[wave][1][lane] = acc1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        uint32_t keep = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+        blk_t s = red[0][keep][t8];
+        for (int w = 1; w < GGM_BLOCK / 64; w++) s = bxor(s, red[w][keep][t8]);
+        unsigned long long *dst = (unsigned long long *)(sums + ((uint64_t)set * 2 + keep) * 8 + t8);
+        atomicXor(dst, ((unsigned long long)s.y << 32) | s.x);
+        atomicXor(dst + 1, ((unsigned long long)s.w << 32) | s.z);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sender: mask level sums with the base OTs, build the last-level 4-tuples (pprf.rs:199-254)
+__global__ void k_sender_treegrp(const blk_t *__restrict__ sums, const blk_t *__restrict__ base /*[tr*depth+d][2]*/,
+                                 blk_t delta, uint32_t parts, uint32_t depth, blk_t *__restrict__ tg_sums,
+                                 blk_t *__restrict__ tg_last) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= parts) return;
+    const uint32_t nsets = parts >> 3, grp = tr >> 3, j = tr & 7;
+    for (uint32_t keep = 0; keep < 2; keep++)
+        for (uint32_t d = 0; d + 1 < depth; d++) {
+            blk_t s = sums[(((uint64_t)d * nsets + grp) * 2 + keep) * 8 + j];
+            tg_sums[(((uint64_t)grp * 2 + keep) * (depth - 1) + d) * 8 + j] =
+                bxor(s, base[((uint64_t)tr * depth + d) * 2 + keep]);
+        }
+    const uint32_t d = depth - 1;
+    blk_t s0 = sums[(((uint64_t)d * nsets + grp) * 2 + 0) * 8 + j];
+    blk_t s1 = sums[(((uint64_t)d * nsets + grp) * 2 + 1) * 8 + j];
+    blk_t o0 = base[((uint64_t)tr * depth + d) * 2 + 0], o1 = base[((uint64_t)tr * depth + d) * 2 + 1];
+    blk_t *lo = tg_last + ((uint64_t)grp * 8 + j) * 4;
+    lo[0] = bxor(s0, cr_hash(te, o0));
+    lo[1] = bxor(bxor(s1, delta), cr_hash(te, bnot(o0)));
+    lo[2] = bxor(s1, cr_hash(te, o1));
+    lo[3] = bxor(bxor(s0, delta), cr_hash(te, bnot(o1)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// receiver helpers
+__device__ __forceinline__ uint64_t active_path(const uint8_t *cb, uint32_t depth) {  // pprf.rs:701-706
+    uint64_t p = 0;
+    for (uint32_t i = 0; i < depth; i++) p |= (uint64_t)(1 ^ cb[i]) << (depth - i - 1);
+    return p;
+}
+
+// level 1 from the first base OT and the first sum (pprf.rs:376-384)
+__global__ void k_recv_init(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
+                            const blk_t *__restrict__ tg_sums, uint32_t parts, uint32_t depth,
+                            blk_t *__restrict__ lvl1) {
+    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= parts) return;
+    uint32_t grp = tr >> 3, j = tr & 7;
+    uint32_t not_ai = choices[(uint64_t)tr * depth];
+    blk_t v = bxor(base[(uint64_t)tr * depth], tg_sums[(((uint64_t)grp * 2 + not_ai) * (depth - 1)) * 8 + j]);
+    lvl1[((uint64_t)grp * 2 + not_ai) * 8 + j] = v;
+    lvl1[((uint64_t)grp * 2 + (not_ai ^ 1)) * 8 + j] = bzero();
+}
+
+// repair the inactive child of the active parent on level d+1 (pprf.rs:456-467)
+__global__ void k_recv_fix(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
+                           const blk_t *__restrict__ tg_sums, const blk_t *__restrict__ my_sums /*level d*/,
+                           uint32_t parts, uint32_t depth, uint32_t d, blk_t *__restrict__ lvl /*level d+1*/) {
+    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= parts) return;
+    uint32_t grp = tr >> 3, j = tr & 7;
+    uint64_t leaf = active_path(choices + (uint64_t)tr * depth, depth);
+    uint64_t active = leaf >> (depth - 1 - d);
+    uint64_t inactive = active ^ 1;
+    uint32_t not_ai = inactive & 1;
+    blk_t *p = lvl + (((uint64_t)grp << (d + 1)) + inactive) * 8 + j;
+    blk_t v = *p;
+    v = bxor(v, tg_sums[(((uint64_t)grp * 2 + not_ai) * (depth - 1) + d) * 8 + j]);
+    v = bxor(v, my_sums[((uint64_t)grp * 2 + not_ai) * 8 + j]);
+    v = bxor(v, base[(uint64_t)tr * depth + d]);
+    *p = v;
+}
+
+// last level: fix both children of the active parent inside V (pprf.rs:474-535)
+__global__ void k_recv_last(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
+                            const blk_t *__restrict__ tg_last, const blk_t *__restrict__ my_sums /*level depth-1*/,
+                            uint32_t parts, uint32_t depth, uint64_t cols, blk_t *__restrict__ V) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= parts) return;
+    const uint32_t nsets = parts >> 3, grp = tr >> 3, j = tr & 7;
+    uint64_t active = active_path(choices + (uint64_t)tr * depth, depth);
+    uint64_t inactive = active ^ 1;
+    uint32_t not_ai = inactive & 1;
+    blk_t o = base[(uint64_t)tr * depth + depth - 1];
+    blk_t ot0 = bxor(tg_last[((uint64_t)grp * 8 + j) * 4 + 2 * not_ai + 0], cr_hash(te, o));
+    blk_t ot1 = bxor(tg_last[((uint64_t)grp * 8 + j) * 4 + 2 * not_ai + 1], cr_hash(te, bnot(o)));
+    uint64_t tile = grp + (uint64_t)nsets * (active >> 4);
+    if (tile >= cols) return;  // pprf.rs:509-519 guard; unreachable for sampled choices
+    blk_t *pi = V + tile * 128 + 8 * (inactive & 15) + j;
+    blk_t *pa = V + tile * 128 + 8 * (active & 15) + j;
+    blk_t inactive_sum = bxor(my_sums[((uint64_t)grp * 2 + not_ai) * 8 + j], *pi);
+    blk_t active_sum = bxor(my_sums[((uint64_t)grp * 2 + (not_ai ^ 1)) * 8 + j], *pa);
+    *pi = bxor(ot0, inactive_sum);
+    *pa = bxor(ot1, active_sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128x128 bit-tile transposes (util/transpose.rs:53-109 semantics, LSB first):
+// out_tile[r] bit j = in_tile[j] bit r. One 128-thread block per tile.
+__global__ void __launch_bounds__(128)
+    k_transpose_tiles(const blk_t *__restrict__ in, uint64_t in_estride, uint64_t in_tstride, blk_t *__restrict__ out,
+                      uint64_t out_estride, uint64_t out_tstride, uint64_t ntiles) {
+    __shared__ uint32_t tile[128][5];  // padded rows
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t j = threadIdx.x;
+        blk_t v = in[t * in_tstride + (uint64_t)j * in_estride];
+        tile[j][0] = v.x;
+        tile[j][1] = v.y;
+        tile[j][2] = v.z;
+        tile[j][3] = v.w;
+        __syncthreads();
+        const uint32_t r = threadIdx.x, rw = r >> 5, rb = r & 31;
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t w = 0;
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) w |= ((tile[32 * q + b][rw] >> rb) & 1u) << b;
+            o[q] = w;
+        }
+        out[t * out_tstride + (uint64_t)r * out_estride] = make_uint4(o[0], o[1], o[2], o[3]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hashes (silent_ot/mod.rs:275-287, 470-482) and MT bits (gmw/src/mul_triple/silent_ot.rs:93-111)
+__global__ void k_sender_hash(const blk_t *__restrict__ B, blk_t delta, uint64_t n, blk_t *__restrict__ out) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    blk_t d = delta;
+    d.x &= ~1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        blk_t m = B[i];
+        m.x &= ~1u;
+        out[2 * i] = cr_hash(te, m);
+        out[2 * i + 1] = cr_hash(te, bxor(m, d));
+    }
+}
+
+__global__ void k_receiver_hash(const blk_t *__restrict__ A, uint64_t n, blk_t *__restrict__ out,
+                                uint64_t *__restrict__ choice_words) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    const uint64_t n_pad = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        blk_t m = i < n ? A[i] : bzero();
+        unsigned long long bal = __ballot(m.x & 1u);
+        m.x &= ~1u;
+        if (i < n) out[i] = cr_hash(te, m);
+        if ((threadIdx.x & 63) == 0) choice_words[i >> 6] = bal;
+    }
+}
+
+// a = lsb(A); b = lsb(m0)^lsb(m1); v = lsb(m0); u = lsb(H(A&~1)); c = a&b ^ u ^ v
+__global__ void k_mt_bits(const blk_t *__restrict__ B, const blk_t *__restrict__ A, blk_t delta, uint64_t n,
+                          uint64_t *__restrict__ wa, uint64_t *__restrict__ wb, uint64_t *__restrict__ wc) {
+    __shared__ uint32_t te[4][256];
+    aes_lds_fill(te);
+    blk_t d = delta;
+    d.x &= ~1u;
+    const uint64_t n_pad = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t a = 0, b = 0, c = 0;
+        if (i < n) {
+            blk_t mb = B[i], ma = A[i];
+            a = ma.x & 1u;
+            mb.x &= ~1u;
+            ma.x &= ~1u;
+            uint32_t m0 = cr_hash(te, mb).x & 1u;
+            uint32_t m1 = cr_hash(te, bxor(mb, d)).x & 1u;
+            uint32_t u = cr_hash(te, ma).x & 1u;
+            b = m0 ^ m1;
+            c = (a & b) ^ u ^ m0;
+        }
+        unsigned long long ba = __ballot(a), bb = __ballot(b), bc = __ballot(c);
+        if ((threadIdx.x & 63) == 0) {
+            wa[i >> 6] = ba;
+            wb[i >> 6] = bb;
+            wc[i >> 6] = bc;
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static uint8_t sbox_host(uint8_t x) {
+    // derive S-box from TE0 byte 1 (TE0 = (2S, S, S, 3S))
+    static const uint32_t te0[256] = {
+#include "aes_te0.inc"
+    };
+    return (uint8_t)(te0[x] >> 8);
+}
+
+void aes_expand_key_host(const uint8_t key[16], aes_rk *out) {
+    static const uint8_t rcon[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80, 0x1b, 0x36};
+    uint8_t rk[176];
+    memcpy(rk, key, 16);
+    for (int i = 4; i < 44; i++) {
+        uint8_t t[4];
+        memcpy(t, rk + 4 * (i - 1), 4);
+        if (i % 4 == 0) {
+            uint8_t u0 = t[0];
+            t[0] = sbox_host(t[1]) ^ rcon[i / 4 - 1];
+            t[1] = sbox_host(t[2]);
+            t[2] = sbox_host(t[3]);
+            t[3] = sbox_host(u0);
+        }
+        for (int k = 0; k < 4; k++) rk[4 * i + k] = rk[4 * (i - 4) + k] ^ t[k];
+    }
+    memcpy(out->w, rk, 176);
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 4096) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
+    const uint32_t depth = (uint32_t)c->conf.depth, nsets = (uint32_t)c->nsets;
+    // sender: levels 0..depth-1 from the roots in lvl_a; receiver: levels 1..depth-1 from level 1 in lvl_b
+    blk_t *cur = receiver ? c->lvl_b : c->lvl_a;
+    blk_t *nxt = receiver ? c->lvl_a : c->lvl_b;
+    for (uint32_t d = receiver ? 1 : 0; d < depth; d++) {
+        uint64_t per_set = (uint64_t)8 << d;
+        unsigned gx = grid_for(per_set, GGM_BLOCK, 256);
+        dim3 grid(gx, nsets);
+        blk_t *lsum = c->sums + (uint64_t)d * nsets * 16;
+        if (d + 1 < depth) {
+            hipLaunchKernelGGL(k_ggm_level<false>, grid, dim3(GGM_BLOCK), 0, c->stream, cur, nxt, d, nsets,
+                               c->conf.cols, lsum);
+            if (receiver)
+                hipLaunchKernelGGL(k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), 0, c->stream, c->d_base,
+                                   c->d_choices, c->d_tg_sums, lsum, (uint32_t)c->conf.parts, depth, d, nxt);
+            blk_t *t = cur;
+            cur = nxt;
+            nxt = t;
+        } else {
+            hipLaunchKernelGGL(k_ggm_level<true>, grid, dim3(GGM_BLOCK), 0, c->stream, cur, V, d, nsets, c->conf.cols,
+                               lsum);
+        }
+    }
+    SOT_HIP(hipGetLastError());
+    return SOT_OK;
+}
+
+int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const void *seed, uint64_t T,
+                      void *tg_sums_out, void *tg_last_out) {
+    const sot_conf &cf = c->conf;
+    if (T == 0 || T > 4096) {
+        sot_set_error("num_threads must be in 1..4096");
+        return SOT_EINVAL;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    // root PRG keys: seed ^ t (pprf.rs:115, Block::from(usize) is the low 64 bits)
+    uint64_t Teff = T < c->nsets ? T : c->nsets;
+    std::vector<aes_rk> rks(Teff);
+    for (uint64_t t = 0; t < Teff; t++) {
+        uint8_t key[16];
+        memcpy(key, seed, 16);
+        uint64_t lo;
+        memcpy(&lo, key, 8);
+        lo ^= t;
+        memcpy(key, &lo, 8);
+        aes_expand_key_host(key, &rks[t]);
+    }
+    if (Teff > c->rks_cap) {
+        if (c->d_rks) hipFree(c->d_rks);
+        SOT_HIP(hipMalloc((void **)&c->d_rks, Teff * sizeof(aes_rk)));
+        c->rks_cap = Teff;
+    }
+    SOT_HIP(hipMemcpyAsync(c->d_rks, rks.data(), Teff * sizeof(aes_rk), hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 32, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
+    blk_t *V = c->role[SOT_ROLE_SENDER].V;
+    hipLaunchKernelGGL(k_roots, dim3((cf.parts + 127) / 128), dim3(128), 0, c->stream, c->d_rks, (uint32_t)T,
+                       (uint32_t)cf.parts, c->lvl_a);
+    SOT_TRY(launch_levels(c, false, V));
+    blk_t d;
+    memcpy(&d, delta, 16);
+    hipLaunchKernelGGL(k_sender_treegrp, dim3((cf.parts + 127) / 128), dim3(128), 0, c->stream, c->sums, c->d_base, d,
+                       (uint32_t)cf.parts, (uint32_t)cf.depth, c->d_tg_sums, c->d_tg_last);
+    SOT_HIP(hipGetLastError());
+    if (tg_sums_out)
+        SOT_HIP(hipMemcpyAsync(tg_sums_out, c->d_tg_sums, sot_treegrp_sums_blocks(&cf) * 16, hipMemcpyDeviceToHost,
+                               c->stream));
+    if (tg_last_out)
+        SOT_HIP(hipMemcpyAsync(tg_last_out, c->d_tg_last, sot_treegrp_last_blocks(&cf) * 16, hipMemcpyDeviceToHost,
+                               c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    c->role[SOT_ROLE_SENDER].expanded = true;
+    c->role[SOT_ROLE_SENDER].encoded = false;
+    return SOT_OK;
+}
+
+int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices, const void *tg_sums,
+                        const void *tg_last) {
+    const sot_conf &cf = c->conf;
+    SOT_HIP(hipSetDevice(c->device));
+    for (uint64_t i = 0; i < cf.base_ot_count; i++)
+        if (choices[i] > 1) {
+            sot_set_error("choices must be 0/1 bytes");
+            return SOT_EINVAL;
+        }
+    SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 16, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(c->d_choices, choices, cf.base_ot_count, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(c->d_tg_sums, tg_sums, sot_treegrp_sums_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(c->d_tg_last, tg_last, sot_treegrp_last_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
+    blk_t *V = c->role[SOT_ROLE_RECEIVER].V;
+    dim3 gt((cf.parts + 127) / 128), bt(128);
+    hipLaunchKernelGGL(k_recv_init, gt, bt, 0, c->stream, c->d_base, c->d_choices, c->d_tg_sums, (uint32_t)cf.parts,
+                       (uint32_t)cf.depth, c->lvl_b);
+    SOT_TRY(launch_levels(c, true, V));
+    hipLaunchKernelGGL(k_recv_last, gt, bt, 0, c->stream, c->d_base, c->d_choices, c->d_tg_last,
+                       c->sums + (cf.depth - 1) * c->nsets * 16, (uint32_t)cf.parts, (uint32_t)cf.depth, cf.cols, V);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    c->role[SOT_ROLE_RECEIVER].expanded = true;
+    c->role[SOT_ROLE_RECEIVER].encoded = false;
+    return SOT_OK;
+}
+
+static int ensure_tmp(sot_ctx *c, uint64_t bytes) {
+    if (c->tmp_bytes >= bytes) return SOT_OK;
+    if (c->d_tmp) hipFree(c->d_tmp);
+    c->d_tmp = nullptr;
+    c->tmp_bytes = 0;
+    SOT_HIP(hipMalloc(&c->d_tmp, bytes));
+    c->tmp_bytes = bytes;
+    return SOT_OK;
+}
+
+int ggm_download_rT(sot_ctx *c, int role, void *out) {
+    const sot_conf &cf = c->conf;
+    if (!c->role[role].expanded) {
+        sot_set_error("download_rT before expand");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    uint64_t bytes = 128 * cf.cols * 16;
+    SOT_TRY(ensure_tmp(c, bytes));
+    hipLaunchKernelGGL(k_transpose_tiles, dim3(grid_for(cf.cols, 1, 8192)), dim3(128), 0, c->stream, c->role[role].V,
+                       (uint64_t)1, (uint64_t)128, (blk_t *)c->d_tmp, cf.cols, (uint64_t)1, cf.cols);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpyAsync(out, c->d_tmp, bytes, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+int ggm_upload_rT(sot_ctx *c, int role, const void *rT) {
+    const sot_conf &cf = c->conf;
+    SOT_HIP(hipSetDevice(c->device));
+    uint64_t bytes = 128 * cf.cols * 16;
+    SOT_TRY(ensure_tmp(c, bytes));
+    SOT_HIP(hipMemcpyAsync(c->d_tmp, rT, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_transpose_tiles, dim3(grid_for(cf.cols, 1, 8192)), dim3(128), 0, c->stream,
+                       (const blk_t *)c->d_tmp, cf.cols, (uint64_t)1, c->role[role].V, (uint64_t)1, (uint64_t)128,
+                       cf.cols);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    c->role[role].expanded = true;
+    c->role[role].encoded = false;
+    return SOT_OK;
+}
+
+int hash_sender(sot_ctx *c, const void *delta, void *msgs_out) {
+    const sot_conf &cf = c->conf;
+    if (!c->role[SOT_ROLE_SENDER].encoded) {
+        sot_set_error("sender_hash before qc_encode");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    SOT_TRY(ensure_tmp(c, cf.n * 32));
+    blk_t d;
+    memcpy(&d, delta, 16);
+    hipLaunchKernelGGL(k_sender_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream,
+                       c->role[SOT_ROLE_SENDER].enc, d, cf.n, (blk_t *)c->d_tmp);
+    SOT_HIP(hipGetLastError());
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 32, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
+    const sot_conf &cf = c->conf;
+    if (!c->role[SOT_ROLE_RECEIVER].encoded) {
+        sot_set_error("receiver_hash before qc_encode");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    SOT_TRY(ensure_tmp(c, cf.n * 32));
+    uint64_t nw = (cf.n + 63) / 64;
+    hipLaunchKernelGGL(k_receiver_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream,
+                       c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_mt);
+    SOT_HIP(hipGetLastError());
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 16, hipMemcpyDeviceToHost, c->stream));
+    if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64_t *cc) {
+    const sot_conf &cf = c->conf;
+    if (!c->role[0].encoded || !c->role[1].encoded) {
+        sot_set_error("mt_bits needs both the sender and the receiver instance encoded");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    uint64_t nw = (cf.n + 63) / 64;
+    blk_t d;
+    memcpy(&d, delta, 16);
+    hipLaunchKernelGGL(k_mt_bits, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream, c->role[0].enc,
+                       c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
+    SOT_HIP(hipGetLastError());
+    if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (b) SOT_HIP(hipMemcpyAsync(b, c->d_mt + nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (cc) SOT_HIP(hipMemcpyAsync(cc, c->d_mt + 2 * nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+int util_transpose128(int device, const void *in, void *out, uint64_t ntiles) {
+    SOT_HIP(hipSetDevice(device));
+    blk_t *din = nullptr, *dout = nullptr;
+    uint64_t bytes = ntiles * 2048;
+    if (ntiles == 0) return SOT_OK;
+    SOT_HIP(hipMalloc((void **)&din, bytes));
+    if (hipMalloc((void **)&dout, bytes) != hipSuccess) {
+        hipFree(din);
+        sot_set_error("hipMalloc failed");
+        return SOT_ENOMEM;
+    }
+    hipMemcpy(din, in, bytes, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_transpose_tiles, dim3(grid_for(ntiles, 1, 8192)), dim3(128), 0, 0, din, (uint64_t)1,
+                       (uint64_t)128, dout, (uint64_t)1, (uint64_t)128, ntiles);
+    hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    hipFree(din);
+    hipFree(dout);
+    if (e != hipSuccess) {
+        sot_set_error("transpose128: %s", hipGetErrorString(e));
+        return SOT_EDEVICE;
+    }
+    return SOT_OK;
+}
+
+int util_aes(int device, const void *key16, const void *in, void *out, uint64_t n, int cr) {
+    SOT_HIP(hipSetDevice(device));
+    if (n == 0) return SOT_OK;
+    aes_rk rk;
+    memset(&rk, 0, sizeof(rk));
+    if (!cr) aes_expand_key_host((const uint8_t *)key16, &rk);
+    blk_t *din = nullptr, *dout = nullptr;
+    uint32_t *drk = nullptr;
+    SOT_HIP(hipMalloc((void **)&din, n * 16));
+    SOT_HIP(hipMalloc((void **)&dout, n * 16));
+    SOT_HIP(hipMalloc((void **)&drk, sizeof(rk)));
+    hipMemcpy(din, in, n * 16, hipMemcpyHostToDevice);
+    hipMemcpy(drk, &rk, sizeof(rk), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_aes_ecb, dim3(grid_for(n, 256, 2048)), dim3(256), 0, 0, drk, din, dout, n, cr);
+    hipError_t e = hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost);
+    hipFree(din);
+    hipFree(dout);
+    hipFree(drk);
+    if (e != hipSuccess) {
+        sot_set_error("aes: %s", hipGetErrorString(e));
+        return SOT_EDEVICE;
+    }
+    return SOT_OK;
+}
+
+int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk_t *d_out, uint64_t nblocks) {
+    aes_rk rk;
+    aes_expand_key_host(key16, &rk);
+    uint32_t *drk = nullptr;
+    SOT_HIP(hipMalloc((void **)&drk, sizeof(rk)));
+    SOT_HIP(hipMemcpyAsync(drk, &rk, sizeof(rk), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_aes_ctr, dim3(grid_for(nblocks, 256, 2048)), dim3(256), 0, c->stream, drk, first, d_out,
+                       nblocks);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    hipFree(drk);
+    return SOT_OK;
+}

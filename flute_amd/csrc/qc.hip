@@ -1,0 +1,762 @@
+// QuasiCyclic dual-LPN encode on gfx950: B[k] = V[k] ^ V[k+P] ^ ((a * V1) mod (x^P - 1))[k]
+//
+// Reference: zappot/src/silent_ot/quasi_cyclic_encode.rs:29-151,262-344 (128 per-row products
+// a * b1_r via bitpolymul's additive FFT over GF(2^128), + b0_r, modp, 128x128 transposes).
+//
+// MI355X formulation: the 128 rows multiply by the same public a, and a Block of the untransposed
+// PPRF output V holds one coefficient of all 128 row polynomials, so the rows are processed bit-sliced
+// (lane = row, bit = 32 consecutive FFT points) and every field operation is an XOR/AND network:
+//   V1 -> 16 bit planes (Kronecker x -> g, 16 bits per element) -> monomial-to-novel basis conversion
+//   -> GF(2^32) (nimber) coordinates, 32 planes -> LCH additive FFT butterflies with Cantor-basis points
+//   -> pointwise multiply by FFT(a) (precomputed bit matrices) -> inverse butterflies -> inverse basis
+//   conversion -> overlap-add back to Blocks T -> fold mod x^P - 1 together with V0 and the short
+//   schoolbook "tail" terms for the few bits of a and V1 above the power-of-two FFT capacity.
+// The math (and the generators of the constant tables) is in gf2fft_model.py / gen_tables.py.
+#include <string.h>
+
+#include <vector>
+
+#include "sot_internal.h"
+
+#define ROWS 128  // bit rows of a Block; lane l of a wave owns rows l and l + 64
+
+static __device__ const uint32_t d_BETA[32] = {
+#include "qc_beta.inc"
+};
+static __device__ const uint32_t d_RTAB[32 * 32] = {
+#include "qc_rtab.inc"
+};
+static __device__ const uint32_t d_MPOS[4 * 8 * 8] = {
+#include "qc_mpos.inc"
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// 32x32 bit transpose, LSB first: on return a[i] bit p == (old a[p]) bit i
+__device__ __forceinline__ void transpose32(uint32_t a[32]) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j;
+            a[k + j] ^= t;
+        }
+    }
+}
+
+// bits b in [0,32) with lo <= b < hi (arguments may be out of range / negative)
+__device__ __forceinline__ uint32_t range_mask(int64_t lo, int64_t hi) {
+    if (lo < 0) lo = 0;
+    if (hi > 32) hi = 32;
+    if (hi <= lo) return 0u;
+    uint32_t top = hi == 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+    return top & ~((1u << lo) - 1u);  // lo < 32 here
+}
+
+// ------------------------------------------------------------------------------------------------
+// receiver with packed choice bits: bit 0 of the leaf vector is replaced by the noise indicator sb
+// (silent_ot/mod.rs:560-574, quasi_cyclic_encode.rs:92-100)
+__global__ void k_clear_lsb(blk_t *__restrict__ V, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t *p = (uint32_t *)(V + i);
+        *p &= ~1u;
+    }
+}
+__global__ void k_set_points(blk_t *__restrict__ V, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t nV) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npts && pts[i] < nV) {
+        uint32_t *p = (uint32_t *)(V + pts[i]);
+        atomicOr(p, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: Blocks -> 16 bit planes. X[(w*16 + t)*ROWS + row] bit p = bit `row` of V1'[16*(32 w + p) + t],
+// V1'[c] = V1[c] ^ V1[c + P] (reduction mod x^P - 1 of the 2*n_blocks*128-bit row), c < lo_bits.
+// One wave per word index w (512 Blocks in, 8 KiB out).
+__global__ void __launch_bounds__(256)
+    k_qc_load(const blk_t *__restrict__ V1, uint64_t v1_len, uint64_t P, uint64_t lo_bits, uint64_t nw_in,
+              uint32_t *__restrict__ X) {
+    __shared__ uint32_t tile[4][512 * 4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+    if (w < nw_in) {
+        for (uint32_t i = lane; i < 512; i += 64) {
+            uint64_t c = w * 512 + i;
+            blk_t v = make_uint4(0, 0, 0, 0);
+            if (c < lo_bits) {
+                v = V1[c];
+                if (c + P < v1_len) {
+                    blk_t u = V1[c + P];
+                    v.x ^= u.x;
+                    v.y ^= u.y;
+                    v.z ^= u.z;
+                    v.w ^= u.w;
+                }
+            }
+            *(blk_t *)&tile[wave][i * 4] = v;
+        }
+    }
+    __syncthreads();
+    if (w >= nw_in) return;
+    const uint32_t t = lane >> 2, q = lane & 3;
+    uint32_t a[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++) a[p] = tile[wave][(16 * p + t) * 4 + q];
+    transpose32(a);
+    uint32_t *dst = X + (w * 16 + t) * ROWS + 32 * q;
+#pragma unroll
+    for (int b = 0; b < 32; b++) dst[b] = a[b];
+}
+
+// public polynomial: row 0 of the plane layout from a packed bit vector, other rows zero (memset before)
+__global__ void k_a_load(const uint32_t *__restrict__ abits, uint64_t nbits, uint64_t nw_in, uint32_t *__restrict__ X) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (w, t)
+    if (idx >= nw_in * 16) return;
+    uint64_t w = idx >> 4;
+    uint32_t t = idx & 15;
+    uint32_t word = 0;
+    for (uint32_t p = 0; p < 32; p++) {
+        uint64_t bit = 16 * (32 * w + p) + t;
+        if (bit < nbits) word |= ((abits[bit >> 5] >> (bit & 31)) & 1u) << p;
+    }
+    X[(w * 16 + t) * ROWS] = word;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: one phase of the monomial <-> novel basis conversion (gf2fft_model.conversion_phases):
+//   out[i] = in[i] ^ m1(l) in[i + D] ^ m2(l) in[i + 2D],  l = i mod chunk, D = half - pw
+//   m1 = (l >= half) ? (l - half < pw) : (l >= pw);  m2 = forward && pw <= l < 2 pw
+// i indexes elements = bit positions along a plane. Thread = (word, plane, row).
+template <int NP>
+__global__ void __launch_bounds__(256)
+    k_conv_phase(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t nwords, uint64_t chunk,
+                 uint64_t pw, uint64_t half, int inverse) {
+    const uint64_t total = nwords * NP * ROWS;
+    const uint64_t D = half - pw;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t wd = idx / (NP * ROWS);
+        const uint64_t rem = idx - wd * (NP * ROWS);  // plane*ROWS + row
+        uint32_t m1, m2;
+        if (chunk >= 32) {
+            int64_t l0 = (int64_t)((32 * wd) & (chunk - 1));
+            m1 = range_mask((int64_t)half - l0, (int64_t)(half + pw) - l0) | range_mask((int64_t)pw - l0, (int64_t)half - l0);
+            m2 = inverse ? 0u : range_mask((int64_t)pw - l0, (int64_t)(2 * pw) - l0);
+        } else {
+            uint32_t c1 = range_mask((int64_t)half, (int64_t)(half + pw)) | range_mask((int64_t)pw, (int64_t)half);
+            uint32_t c2 = inverse ? 0u : range_mask((int64_t)pw, (int64_t)(2 * pw));
+            for (uint32_t s = (uint32_t)chunk; s < 32; s <<= 1) {
+                c1 |= c1 << s;
+                c2 |= c2 << s;
+            }
+            m1 = c1;
+            m2 = c2;
+        }
+        uint32_t v = in[idx];
+        if (m1) {
+            uint64_t ws = wd + (D >> 5);
+            uint32_t sh = D & 31;
+            uint32_t lo = ws < nwords ? in[ws * (NP * ROWS) + rem] : 0u;
+            uint32_t hi = (sh && ws + 1 < nwords) ? in[(ws + 1) * (NP * ROWS) + rem] : 0u;
+            uint32_t s = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+            v ^= s & m1;
+        }
+        if (m2) {
+            uint64_t D2 = 2 * D;
+            uint64_t ws = wd + (D2 >> 5);
+            uint32_t sh = D2 & 31;
+            uint32_t lo = ws < nwords ? in[ws * (NP * ROWS) + rem] : 0u;
+            uint32_t hi = (sh && ws + 1 < nwords) ? in[(ws + 1) * (NP * ROWS) + rem] : 0u;
+            uint32_t s = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+            v ^= s & m2;
+        }
+        out[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// twiddle matrices. TW[tbl][idx][k] = row k of "multiply by point(2 * (idx << 10 tbl))";
+// TWC[tbl][idx] = that point. Rows/points of a block index j are the XOR over tbl of entry (j >> 10 tbl) & 1023.
+#define TW_TABLES 3
+__global__ void k_build_tw(uint32_t *__restrict__ TW, uint32_t *__restrict__ TWC) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (tbl, e, k)
+    if (idx >= TW_TABLES * 1024 * 32) return;
+    uint32_t k = idx & 31, e = (idx >> 5) & 1023, tbl = idx >> 15;
+    uint64_t p = 2ull * ((uint64_t)e << (10 * tbl));
+    uint32_t c = 0;
+    for (int i = 0; i < 32; i++)
+        if ((p >> i) & 1) c ^= d_BETA[i];
+    uint32_t row = 0;
+    for (int t = 0; t < 32; t++)
+        if ((c >> t) & 1) row ^= d_RTAB[t * 32 + k];
+    TW[idx] = row;
+    if (k == 0) TWC[tbl * 1024 + e] = c;
+}
+
+struct twid {
+    uint32_t c;        // the field element (nimber)
+    uint32_t row[32];  // row k: bit j set <=> output bit k takes input bit j
+};
+
+__device__ __forceinline__ void load_twid(const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC, uint32_t j,
+                                          twid &tw) {
+    // j is wave-uniform: everything below lives in SGPRs
+    const uint32_t e0 = j & 1023, e1 = (j >> 10) & 1023, e2 = (j >> 20) & 1023;
+    tw.c = TWC[e0] ^ TWC[1024 + e1] ^ TWC[2048 + e2];
+#pragma unroll
+    for (int k = 0; k < 32; k++)
+        tw.row[k] = TW[e0 * 32 + k] ^ TW[(1024 + e1) * 32 + k] ^ TW[(2048 + e2) * 32 + k];
+}
+
+// t = c (x) y on two independent bit-sliced operands (rows l and l+64); the matrix is block diagonal
+// with identical BxB blocks when c lies in the subfield GF(2^B)
+template <int B>
+__device__ __forceinline__ void mul_blocks(const twid &tw, const uint32_t y0[32], const uint32_t y1[32], uint32_t t0[32],
+                                           uint32_t t1[32]) {
+#pragma unroll
+    for (int blk = 0; blk < 32 / B; blk++) {
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            uint32_t a0 = 0, a1 = 0;
+            const uint32_t r = tw.row[k];
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+                const uint32_t m = 0u - ((r >> j) & 1u);
+                a0 ^= y0[blk * B + j] & m;
+                a1 ^= y1[blk * B + j] & m;
+            }
+            t0[blk * B + k] = a0;
+            t1[blk * B + k] = a1;
+        }
+    }
+}
+
+__device__ __forceinline__ void mul_uniform(const twid &tw, const uint32_t y0[32], const uint32_t y1[32], uint32_t t0[32],
+                                            uint32_t t1[32]) {
+    const uint32_t c = tw.c;
+    if (c < (1u << 8)) {
+        mul_blocks<8>(tw, y0, y1, t0, t1);
+    } else if (c < (1u << 16)) {
+        mul_blocks<16>(tw, y0, y1, t0, t1);
+    } else {
+        mul_blocks<32>(tw, y0, y1, t0, t1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: Kronecker pack (16 polynomial-coefficient planes -> 32 nimber-coordinate planes, element = sum b_t g^t)
+// fused with butterfly level ell-1, whose upper input half is zero (twiddle point(0) = 0): both halves = x.
+__global__ void __launch_bounds__(256)
+    k_qc_expand(const uint32_t *__restrict__ X, uint32_t *__restrict__ D, uint64_t nw_in) {
+    static constexpr uint32_t GROW[32] = {
+#include "qc_grow.inc"
+    };
+    const uint64_t total = nw_in * ROWS;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = idx / ROWS;
+        const uint32_t row = idx % ROWS;
+        uint32_t x[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) x[t] = X[(w * 16 + t) * ROWS + row];
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            uint32_t y = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+                if ((GROW[k] >> t) & 1) y ^= x[t];
+            D[(w * 32 + k) * ROWS + row] = y;
+            D[((w + nw_in) * 32 + k) * ROWS + row] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: one butterfly level i >= 5 (pairs of words at distance 2^(i-5)), forward:  x ^= tw*y; y ^= x
+//                                                                        inverse:  y ^= x; x ^= tw*y
+// One wave per word pair; lane l handles rows l and l+64.
+template <bool INV>
+__global__ void __launch_bounds__(256)
+    k_fft_level(uint32_t *__restrict__ D, uint64_t npairs, uint32_t d /* = i - 5 */, const uint32_t *__restrict__ TW,
+                const uint32_t *__restrict__ TWC) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t pi = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= npairs) return;
+    pi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pi >> 32)) << 32) |
+         __builtin_amdgcn_readfirstlane((uint32_t)pi);
+    const uint64_t w0 = ((pi >> d) << (d + 1)) | (pi & (((uint64_t)1 << d) - 1));
+    const uint64_t w1 = w0 + ((uint64_t)1 << d);
+    const uint32_t j = (uint32_t)(pi >> d);
+    twid tw;
+    load_twid(TW, TWC, j, tw);
+    uint32_t *px = D + w0 * 32 * ROWS + lane;
+    uint32_t *py = D + w1 * 32 * ROWS + lane;
+    uint32_t x0[32], x1[32], y0[32], y1[32], t0[32], t1[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        x0[k] = px[k * ROWS];
+        x1[k] = px[k * ROWS + 64];
+        y0[k] = py[k * ROWS];
+        y1[k] = py[k * ROWS + 64];
+    }
+    if (INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            y0[k] ^= x0[k];
+            y1[k] ^= x1[k];
+        }
+    }
+    if (tw.c != 0) {
+        mul_uniform(tw, y0, y1, t0, t1);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            x0[k] ^= t0[k];
+            x1[k] ^= t1[k];
+        }
+    }
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            y0[k] ^= x0[k];
+            y1[k] ^= x1[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        px[k * ROWS] = x0[k];
+        px[k * ROWS + 64] = x1[k];
+        py[k * ROWS] = y0[k];
+        py[k * ROWS + 64] = y1[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: the five intra-word levels (4..0 forward, 0..4 inverse), optionally with the pointwise multiply by
+// FFT(a) in between. Level i pairs bit positions p and p + 2^i; the twiddle of position p is
+// point(2*((32w+p) >> (i+1))) = point(w << (5-i)) ^ point(2*(p >> (i+1))): a wave-uniform part and a
+// per-position part that lies in GF(2^8) (compile-time masks QC_MPOS).
+__device__ __forceinline__ uint32_t lowmask(int i) {
+    return i == 0 ? 0x55555555u : i == 1 ? 0x33333333u : i == 2 ? 0x0F0F0F0Fu : i == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+}
+
+template <int I, bool INV>
+__device__ __forceinline__ void low_level(uint32_t W0[32], uint32_t W1[32], uint64_t w, const uint32_t *__restrict__ TW,
+                                          const uint32_t *__restrict__ TWC) {
+    const uint32_t A = lowmask(I);
+    constexpr int SH = 1 << I;
+    uint32_t v0[32], v1[32], t0[32], t1[32];
+    if (INV) {  // y ^= x first
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            W0[k] ^= (W0[k] & A) << SH;
+            W1[k] ^= (W1[k] & A) << SH;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        v0[k] = (W0[k] >> SH) & A;
+        v1[k] = (W1[k] >> SH) & A;
+    }
+    // uniform part: block index of the word's first position at this level
+    const uint32_t ju = (uint32_t)(w << (4 - I));
+    twid tw;
+    load_twid(TW, TWC, ju, tw);
+    if (tw.c != 0) {
+        mul_uniform(tw, v0, v1, t0, t1);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; k++) t0[k] = t1[k] = 0;
+    }
+    if (I < 4) {  // per-position part, GF(2^8) blocks
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t m = d_MPOS[(I * 8 + k) * 8 + j];
+                    a0 ^= v0[blk * 8 + j] & m;
+                    a1 ^= v1[blk * 8 + j] & m;
+                }
+                t0[blk * 8 + k] ^= a0;
+                t1[blk * 8 + k] ^= a1;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        W0[k] ^= t0[k];  // t only has bits at the x positions
+        W1[k] ^= t1[k];
+    }
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            W0[k] ^= (W0[k] & A) << SH;
+            W1[k] ^= (W1[k] & A) << SH;
+        }
+    }
+}
+
+// MODE 0: forward low levels only (used for FFT(a)); MODE 1: forward, multiply by FFT(a), inverse
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    k_fft_low(uint32_t *__restrict__ D, uint64_t nw, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC,
+              const uint32_t *__restrict__ Amat) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nw) return;
+    w = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+        __builtin_amdgcn_readfirstlane((uint32_t)w);
+    uint32_t *p = D + w * 32 * ROWS + lane;
+    uint32_t W0[32], W1[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        W0[k] = p[k * ROWS];
+        W1[k] = p[k * ROWS + 64];
+    }
+    low_level<4, false>(W0, W1, w, TW, TWC);
+    low_level<3, false>(W0, W1, w, TW, TWC);
+    low_level<2, false>(W0, W1, w, TW, TWC);
+    low_level<1, false>(W0, W1, w, TW, TWC);
+    low_level<0, false>(W0, W1, w, TW, TWC);
+    if (MODE == 1) {
+        const uint32_t *M = Amat + w * 1024;  // wave-uniform address
+        uint32_t t0[32], t1[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t m = M[k * 32 + j];
+                a0 ^= W0[j] & m;
+                a1 ^= W1[j] & m;
+            }
+            t0[k] = a0;
+            t1[k] = a1;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            W0[k] = t0[k];
+            W1[k] = t1[k];
+        }
+        low_level<0, true>(W0, W1, w, TW, TWC);
+        low_level<1, true>(W0, W1, w, TW, TWC);
+        low_level<2, true>(W0, W1, w, TW, TWC);
+        low_level<3, true>(W0, W1, w, TW, TWC);
+        low_level<4, true>(W0, W1, w, TW, TWC);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        p[k * ROWS] = W0[k];
+        p[k * ROWS + 64] = W1[k];
+    }
+}
+
+// Amat[w][k][j] bit p = bit k of (FFT(a)[32 w + p] (x) 2^j); FFT(a) is row 0 of Da
+__global__ void k_build_amat(const uint32_t *__restrict__ Da, uint64_t nw, uint32_t *__restrict__ Amat) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (w, k, j)
+    if (idx >= nw * 1024) return;
+    const uint64_t w = idx >> 10;
+    const uint32_t k = (idx >> 5) & 31, j = idx & 31;
+    uint32_t m = 0;
+    for (int t = 0; t < 32; t++)
+        if ((d_RTAB[t * 32 + k] >> j) & 1) m ^= Da[(w * 32 + t) * ROWS];
+    Amat[idx] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: nimber coordinates -> coefficients on 1, g, ..., g^31 (in place), all words
+__global__ void __launch_bounds__(256) k_qc_unpack(uint32_t *__restrict__ D, uint64_t nw) {
+    static constexpr uint32_t GINVROW[32] = {
+#include "qc_ginvrow.inc"
+    };
+    const uint64_t total = nw * ROWS;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = idx / ROWS;
+        const uint32_t row = idx % ROWS;
+        uint32_t *p = D + w * 32 * ROWS + row;
+        uint32_t x[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) x[k] = p[k * ROWS];
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
+            uint32_t y = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                if ((GINVROW[t] >> k) & 1) y ^= x[k];
+            p[t * ROWS] = y;
+        }
+    }
+}
+
+// K9: overlap-add of the 31-bit product elements and transpose back to Blocks:
+// T[16*(32w+p) + t] bit row = C_t[w] ^ (C_{16+t}[w] << 1 | C_{16+t}[w-1] >> 31), bit p
+__global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ D, uint64_t nw, blk_t *__restrict__ T) {
+    __shared__ uint32_t tile[4][512 * 4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+    if (w < nw) {
+        const uint32_t t = lane >> 2, q = lane & 3;
+        uint32_t a[32];
+        const uint32_t *lo = D + (w * 32 + t) * ROWS + 32 * q;
+        const uint32_t *hi = D + (w * 32 + 16 + t) * ROWS + 32 * q;
+        const uint32_t *hp = w ? D + ((w - 1) * 32 + 16 + t) * ROWS + 32 * q : nullptr;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            uint32_t v = lo[b] ^ (hi[b] << 1);
+            if (hp) v ^= hp[b] >> 31;
+            a[b] = v;
+        }
+        transpose32(a);
+#pragma unroll
+        for (int p = 0; p < 32; p++) tile[wave][(16 * p + t) * 4 + q] = a[p];
+    }
+    __syncthreads();
+    if (w >= nw) return;
+    for (uint32_t i = lane; i < 512; i += 64) T[w * 512 + i] = *(blk_t *)&tile[wave][i * 4];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: fold mod x^P - 1, add V0, add the tail terms:
+//   B[k] = V0[k] ^ V0[k+P] ^ T[k] ^ T[k+P] ^ sum_{i: a_hi[i]} V1'[(k - S - i) mod P]
+//                                         ^ sum_{j < tail} a_lo[(k - S - j) mod P] V1'[S + j]
+// V0 = V[0 .. nb128), V1' = (V1 mod x^P - 1). a2 = a' repeated twice as a bit vector.
+__device__ __forceinline__ blk_t ld_v1p(const blk_t *V1, uint64_t v1_len, uint64_t P, uint64_t c) {
+    blk_t v = V1[c];
+    if (c + P < v1_len) {
+        blk_t u = V1[c + P];
+        v.x ^= u.x;
+        v.y ^= u.y;
+        v.z ^= u.z;
+        v.w ^= u.w;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+    k_qc_final(const blk_t *__restrict__ V, uint64_t nb128, uint64_t P, uint64_t S, uint64_t tail, uint64_t n,
+               const blk_t *__restrict__ T, uint64_t t_len, const uint32_t *__restrict__ a2,
+               const uint32_t *__restrict__ a_hi /* tail bits, packed */, blk_t *__restrict__ out) {
+    const blk_t *V1 = V + nb128;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        blk_t r = V[k];
+        if (k + P < nb128) {
+            blk_t u = V[k + P];
+            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+        }
+        for (uint64_t m = k; m < t_len; m += P) {
+            blk_t u = T[m];
+            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+        }
+        if (tail) {
+            // q = (k - S) mod P
+            uint64_t q = k >= S ? k - S : k + P - S;
+            for (uint64_t i = 0; i < tail; i++) {
+                if ((a_hi[i >> 5] >> (i & 31)) & 1u) {
+                    uint64_t c = q >= i ? q - i : q + P - i;
+                    blk_t u = ld_v1p(V1, nb128, P, c);
+                    r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+                }
+            }
+            for (uint64_t j = 0; j < tail; j++) {
+                uint64_t c = q >= j ? q - j : q + P - j;  // index into a'
+                if (c < S) {
+                    uint32_t bit = (a2[c >> 5] >> (c & 31)) & 1u;
+                    if (bit) {
+                        blk_t u = ld_v1p(V1, nb128, P, S + j);
+                        r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+                    }
+                }
+            }
+        }
+        out[k] = r;
+    }
+}
+
+// ================================================================================================
+// host orchestration
+// ================================================================================================
+struct phase_t {
+    uint64_t chunk, pw, half;
+};
+
+static void conv_rec(std::vector<phase_t> &ph, uint32_t nbits, uint64_t unit) {
+    if (nbits <= 1) return;
+    uint32_t t = 0;
+    while ((1u << (t + 1)) < nbits) t++;
+    uint32_t qb = 1u << t, R = nbits - qb;
+    for (int pb = (int)R - 1; pb >= 0; pb--) {
+        uint64_t pw = ((uint64_t)1 << pb) * unit;
+        uint64_t half = ((uint64_t)1 << (pb + qb)) * unit;
+        ph.push_back({2 * half, pw, half});
+    }
+    conv_rec(ph, R, unit << qb);
+    conv_rec(ph, qb, unit);
+}
+
+static inline unsigned gridn(uint64_t n, unsigned block, unsigned cap = 65535u * 16) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+// runs the conversion on `bufs[cur]`, ping-ponging; returns index of the buffer holding the result
+template <int NP>
+static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, uint64_t nwords, bool inverse) {
+    std::vector<phase_t> ph;
+    conv_rec(ph, ell_elems, 1);
+    const uint64_t total = nwords * NP * ROWS;
+    const unsigned grid = gridn(total, 256, 1u << 20);
+    if (!inverse) {
+        for (size_t i = 0; i < ph.size(); i++) {
+            hipLaunchKernelGGL(k_conv_phase<NP>, dim3(grid), dim3(256), 0, c->stream, bufs[cur], bufs[cur ^ 1], nwords,
+                               ph[i].chunk, ph[i].pw, ph[i].half, 0);
+            cur ^= 1;
+        }
+    } else {
+        for (size_t i = ph.size(); i-- > 0;) {
+            hipLaunchKernelGGL(k_conv_phase<NP>, dim3(grid), dim3(256), 0, c->stream, bufs[cur], bufs[cur ^ 1], nwords,
+                               ph[i].chunk, ph[i].pw, ph[i].half, 1);
+            cur ^= 1;
+        }
+    }
+    return cur;
+}
+
+// forward transform of the 16-plane input in X[xcur] into D0 (levels ell-1 .. 5); low levels left to the caller
+static int forward_to_D(sot_ctx *c, int xcur) {
+    const qc_geom &g = c->g;
+    uint32_t *xb[2] = {c->X0, c->X1};
+    xcur = run_conversion<16>(c, xb, xcur, g.ell - 1, g.nw_in, false);
+    hipLaunchKernelGGL(k_qc_expand, dim3(gridn(g.nw_in * ROWS, 256, 1u << 20)), dim3(256), 0, c->stream, xb[xcur],
+                       c->D0, g.nw_in);
+    const uint64_t npairs = g.nw / 2;
+    for (int i = (int)g.ell - 2; i >= 5; i--)
+        hipLaunchKernelGGL(k_fft_level<false>, dim3(gridn(npairs, 4)), dim3(256), 0, c->stream, c->D0, npairs,
+                           (uint32_t)(i - 5), c->TW, c->TWC);
+    SOT_HIP(hipGetLastError());
+    return SOT_OK;
+}
+
+static int upload_a_and_transform(sot_ctx *c) {
+    const sot_conf &cf = c->conf;
+    const qc_geom &g = c->g;
+    const uint64_t nb128 = cf.n_blocks * 128;
+    // a = first n64 u64 of AesRng(seed = Block::from(1)) (quasi_cyclic_encode.rs:127-138)
+    blk_t *d_araw = nullptr;
+    SOT_HIP(hipMalloc((void **)&d_araw, cf.n_blocks * 16));
+    uint8_t key[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int rc = util_aes_ctr_device(c, key, 0, d_araw, cf.n_blocks);
+    std::vector<uint32_t> a(cf.n_blocks * 4 + 2);
+    if (rc == SOT_OK && hipMemcpy(a.data(), d_araw, cf.n_blocks * 16, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = SOT_EDEVICE;
+    hipFree(d_araw);
+    SOT_TRY(rc);
+    // a' = a mod (x^P - 1): fold bits [P, nb128) onto [0, nb128 - P)
+    auto getbit = [&](uint64_t i) -> uint32_t { return (a[i >> 5] >> (i & 31)) & 1u; };
+    const uint64_t P = cf.P;
+    std::vector<uint32_t> ap((P + 31) / 32 + 2, 0);
+    for (uint64_t w = 0; w < (P + 31) / 32; w++) ap[w] = a[w];
+    if (P & 31) ap[P / 32] &= (1u << (P & 31)) - 1u;
+    for (uint64_t i = P; i < nb128; i++)
+        if (getbit(i)) ap[(i - P) >> 5] ^= 1u << ((i - P) & 31);
+    // tail bits a'[S .. P)
+    c->a_hi_host.assign((g.tail + 31) / 32 + 1, 0);
+    for (uint64_t i = 0; i < g.tail; i++)
+        if ((ap[(g.S + i) >> 5] >> ((g.S + i) & 31)) & 1u) c->a_hi_host[i >> 5] |= 1u << (i & 31);
+    SOT_HIP(hipMemcpy(c->a2, ap.data(), ap.size() * 4, hipMemcpyHostToDevice));
+    SOT_HIP(hipMemcpy(c->a_hi, c->a_hi_host.data(), c->a_hi_host.size() * 4, hipMemcpyHostToDevice));
+    // FFT(a_lo): row 0 of the plane layout
+    SOT_HIP(hipMemsetAsync(c->X0, 0, g.nw_in * 16 * ROWS * 4, c->stream));
+    hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw_in * 16, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw_in,
+                       c->X0);
+    SOT_TRY(forward_to_D(c, 0));
+    hipLaunchKernelGGL(k_fft_low<0>, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, c->D0, g.nw, c->TW, c->TWC,
+                       (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_build_amat, dim3(gridn(g.nw * 1024, 256)), dim3(256), 0, c->stream, c->D0, g.nw, c->Amat);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+int qc_init(sot_ctx *c) {
+    const sot_conf &cf = c->conf;
+    qc_geom &g = c->g;
+    const uint64_t nb128 = cf.n_blocks * 128;
+    if (nb128 < cf.P) {
+        sot_set_error("unsupported geometry: n_blocks*128 < P");
+        return SOT_EINVAL;
+    }
+    // FFT capacity S = 8 L bits per operand; up to QC_TAIL_MAX bits above it go through the tail terms
+    const uint64_t TAIL_MAX = 256;
+    uint32_t ell = 11;
+    while ((8ull << ell) + TAIL_MAX < cf.P) ell++;
+    g.ell = ell;
+    g.L = 1ull << ell;
+    g.S = 8 * g.L;
+    g.tail = cf.P > g.S ? cf.P - g.S : 0;
+    g.lo_bits = cf.P < g.S ? cf.P : g.S;
+    g.nw_in = g.L / 64;
+    g.nw = g.L / 32;
+    if (ell > 24) {
+        sot_set_error("n too large for the twiddle tables");
+        return SOT_EINVAL;
+    }
+    SOT_TRY(dev_alloc(c, (void **)&c->X0, g.nw_in * 16 * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->X1, g.nw_in * 16 * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->D0, g.nw * 32 * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->D1, g.nw * 32 * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->Amat, g.nw * 1024 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->T, 2 * g.S * 16));
+    SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 1024 * 32 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 1024 * 4));
+    hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 1024 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
+    SOT_HIP(hipGetLastError());
+    return upload_a_and_transform(c);
+}
+
+void qc_free(sot_ctx *c) {
+    void *ptrs[] = {c->X0, c->X1, c->D0, c->D1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+}
+
+int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
+    const sot_conf &cf = c->conf;
+    const qc_geom &g = c->g;
+    SOT_HIP(hipSetDevice(c->device));
+    blk_t *V = c->role[role].V;
+    const uint64_t nb128 = cf.n_blocks * 128;
+    const uint64_t nV = cf.cols * 128;
+    if (role == SOT_ROLE_RECEIVER) {
+        SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), 0, c->stream, V, nV);
+        hipLaunchKernelGGL(k_set_points, dim3((npoints + 127) / 128), dim3(128), 0, c->stream, V, c->d_points,
+                           (uint32_t)npoints, nV);
+    }
+    hipLaunchKernelGGL(k_qc_load, dim3(gridn(g.nw_in, 4)), dim3(256), 0, c->stream, V + nb128, nb128, cf.P, g.lo_bits,
+                       g.nw_in, c->X0);
+    SOT_TRY(forward_to_D(c, 0));
+    hipLaunchKernelGGL(k_fft_low<1>, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, c->D0, g.nw, c->TW, c->TWC,
+                       c->Amat);
+    const uint64_t npairs = g.nw / 2;
+    for (int i = 5; i < (int)g.ell; i++)
+        hipLaunchKernelGGL(k_fft_level<true>, dim3(gridn(npairs, 4)), dim3(256), 0, c->stream, c->D0, npairs,
+                           (uint32_t)(i - 5), c->TW, c->TWC);
+    hipLaunchKernelGGL(k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), 0, c->stream, c->D0, g.nw);
+    uint32_t *db[2] = {c->D0, c->D1};
+    int cur = run_conversion<32>(c, db, 0, g.ell, g.nw, true);
+    hipLaunchKernelGGL(k_qc_store, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, db[cur], g.nw, c->T);
+    hipLaunchKernelGGL(k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), 0, c->stream, V, nb128, cf.P, g.S, g.tail,
+                       cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    c->role[role].encoded = true;
+    return SOT_OK;
+}

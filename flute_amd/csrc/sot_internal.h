@@ -1,0 +1,105 @@
+// Internal declarations shared by the HIP translation units of libflute_sot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/flute_sot.h"
+
+// 16-byte Block as four little-endian 32-bit words (word 0 = bits 0..31)
+typedef uint4 blk_t;
+
+void sot_set_error(const char *fmt, ...);
+
+#define SOT_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            sot_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SOT_EDEVICE;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define SOT_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != SOT_OK) return _rc; \
+    } while (0)
+
+// AES-128 expanded key: 44 little-endian words
+struct aes_rk {
+    uint32_t w[44];
+};
+void aes_expand_key_host(const uint8_t key[16], aes_rk *out);
+
+// geometry of the GF(2^32) additive-FFT product used by the QC encode
+struct qc_geom {
+    uint32_t ell;      // log2 L, L = number of evaluation points
+    uint64_t L;        // points; each operand holds at most L/2 elements of 16 bits
+    uint64_t S;        // bits per operand handled by the FFT = 8 L
+    uint64_t tail;     // P - S if P > S else 0 (handled by the schoolbook tail terms)
+    uint64_t lo_bits;  // min(P, S)
+    uint64_t nw_in;    // words per plane of the 16-plane input  = L / 64
+    uint64_t nw;       // words per plane of the 32-plane domain = L / 32
+};
+
+struct role_state {
+    blk_t *V = nullptr;        // leaves, interleaved order, cols*128 Blocks (rT before the bit transposes)
+    blk_t *enc = nullptr;      // encoded output, n Blocks (B for the sender, A for the receiver)
+    bool expanded = false;
+    bool encoded = false;
+};
+
+struct sot_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    sot_conf conf;
+    qc_geom g;
+    uint64_t nsets = 0;  // parts / 8
+    uint64_t dev_bytes = 0;
+    role_state role[2];
+    // GGM scratch
+    blk_t *lvl_a = nullptr, *lvl_b = nullptr;  // ping-pong interior levels
+    blk_t *sums = nullptr;                     // [depth][nsets][2][8] Blocks
+    blk_t *d_base = nullptr;                   // base OTs (sender: pairs)
+    uint8_t *d_choices = nullptr;
+    blk_t *d_tg_sums = nullptr, *d_tg_last = nullptr;
+    uint32_t *d_rks = nullptr;  // root PRG round keys, [T][44]
+    uint64_t rks_cap = 0;
+    // QC scratch
+    uint32_t *X0 = nullptr, *X1 = nullptr;  // 16-plane input domain, ping-pong
+    uint32_t *D0 = nullptr, *D1 = nullptr;  // 32-plane FFT domain, ping-pong
+    uint32_t *TW = nullptr, *TWC = nullptr; // twiddle matrix tables
+    uint32_t *Amat = nullptr;               // per-word multiply-by-FFT(a) bit matrices [nw][32][32]
+    blk_t *T = nullptr;                     // product a_lo * b_lo in Block form, 2 S Blocks
+    uint32_t *a2 = nullptr;                 // a mod (x^P - 1), bit vector repeated twice (words)
+    uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
+    std::vector<uint32_t> a_hi_host;
+    uint64_t *d_points = nullptr;
+    // MT bits
+    uint64_t *d_mt = nullptr;  // a | b | c words
+    void *d_tmp = nullptr;     // download staging
+    uint64_t tmp_bytes = 0;
+};
+
+// ---- ggm.hip
+int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const void *seed, uint64_t T,
+                      void *tg_sums_out, void *tg_last_out);
+int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices, const void *tg_sums,
+                        const void *tg_last);
+int ggm_download_rT(sot_ctx *c, int role, void *out);
+int ggm_upload_rT(sot_ctx *c, int role, const void *rT);
+int hash_sender(sot_ctx *c, const void *delta, void *msgs_out);
+int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out);
+int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64_t *cc);
+int util_transpose128(int device, const void *in, void *out, uint64_t ntiles);
+int util_aes(int device, const void *key16, const void *in, void *out, uint64_t n, int cr_hash);
+int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk_t *d_out, uint64_t nblocks);
+
+// ---- qc.hip
+int qc_init(sot_ctx *c);
+void qc_free(sot_ctx *c);
+int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints);
+
+int dev_alloc(sot_ctx *c, void **p, uint64_t bytes);

@@ -1,0 +1,87 @@
+"""ctypes loader for libflute_sot.so (C ABI: include/flute_sot.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflute_sot.so")
+_LIB = None
+
+
+class SotError(RuntimeError):
+    pass
+
+
+class Conf(C.Structure):
+    """sot_conf == QuasiCyclicConf + PprfConfig (quasi_cyclic_encode.rs:156-233, pprf.rs:40-44)."""
+    _fields_ = [(k, C.c_uint64) for k in
+                ("n", "scaler", "P", "parts", "size_per", "N2", "N", "depth",
+                 "n_blocks", "n64", "cols", "base_ot_count")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+EXPORTS = [
+    "sot_last_error", "sot_device_count", "sot_configure", "sot_ctx_create", "sot_ctx_destroy", "sot_ctx_conf",
+    "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
+    "sot_sender_expand", "sot_receiver_expand", "sot_receiver_points", "sot_download_rT", "sot_qc_encode",
+    "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_random_silent_send",
+    "sot_random_silent_receive", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
+]
+
+
+def load_library():
+    """Loads the HIP library. Raises SotError if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SotError("libflute_sot.so is missing: run `make -C flute_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    P, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.sot_last_error.restype = C.c_char_p
+    L.sot_device_count.restype = i32
+    L.sot_configure.argtypes = [u64, u64, u64, C.POINTER(Conf)]
+    L.sot_ctx_create.argtypes = [u64, u64, i32, C.POINTER(P)]
+    L.sot_ctx_destroy.argtypes = [P]
+    L.sot_ctx_destroy.restype = None
+    L.sot_ctx_conf.argtypes = [P, C.POINTER(Conf)]
+    L.sot_ctx_device_bytes.argtypes = [P]
+    L.sot_ctx_device_bytes.restype = u64
+    L.sot_ctx_sync.argtypes = [P]
+    L.sot_ctx_stream.argtypes = [P]
+    L.sot_ctx_stream.restype = P
+    L.sot_treegrp_sums_blocks.argtypes = [C.POINTER(Conf)]
+    L.sot_treegrp_sums_blocks.restype = C.c_size_t
+    L.sot_treegrp_last_blocks.argtypes = [C.POINTER(Conf)]
+    L.sot_treegrp_last_blocks.restype = C.c_size_t
+    L.sot_sender_expand.argtypes = [P, P, P, P, u64, P, P]
+    L.sot_receiver_expand.argtypes = [P, P, P, P, P]
+    L.sot_receiver_points.argtypes = [C.POINTER(Conf), P, P]
+    L.sot_download_rT.argtypes = [P, i32, P]
+    L.sot_qc_encode.argtypes = [P, i32, P, u64]
+    L.sot_download_encoded.argtypes = [P, i32, P]
+    L.sot_sender_hash.argtypes = [P, P, P]
+    L.sot_receiver_hash.argtypes = [P, P, P]
+    L.sot_mt_bits.argtypes = [P, P, P, P, P]
+    L.sot_random_silent_send.argtypes = [P, P, P, P, u64, P, P, P]
+    L.sot_random_silent_receive.argtypes = [P, P, P, P, P, P, P]
+    L.sot_transpose128.argtypes = [i32, P, P, u64]
+    L.sot_aes128_encrypt.argtypes = [i32, P, P, P, u64]
+    L.sot_cr_hash.argtypes = [i32, P, P, u64]
+    L.sot_qc_dual_encode_host.argtypes = [P, i32, P, P, u64, P]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int or name.startswith("sot_") and fn.restype == C.c_int:
+            fn.restype = i32
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SotError("libflute_sot error %d: %s" % (rc, load_library().sot_last_error().decode()))
+
+
+def device_count():
+    return int(load_library().sot_device_count())

@@ -1,0 +1,143 @@
+/*
+ * flute_sot.h -- C ABI of libflute_sot: MI355X (gfx950) silent-OT correlation engine for FLUTE.
+ *
+ * Drop-in boundary for the local, data-parallel expansion that runs after the base-OT seeds are
+ * exchanged (zappot silent_ot sender/receiver + gmw SilentMtProvider bit derivation). The reference
+ * has one FFI seam on this path (crates/bitpolymul-sys, a bindgen-style `extern "C"` block with raw
+ * pointers and lengths); this header sits one level higher so that whole stages stay on the GPU.
+ * A Rust `-sys` crate binds these symbols exactly as bitpolymul-sys binds bitpolymul2
+ * (see INTEGRATION.md for the extern block and the call sites that change).
+ *
+ * Conventions
+ *  - Block = 16 bytes, little-endian u128 (zappot/src/util/block.rs:17-21).
+ *  - every function returns 0 on success, a negative SOT_E* code otherwise; sot_last_error()
+ *    returns a thread-local message. Nothing calls exit()/abort() (the reference's C layer does:
+ *    bitpolymul2/encode.c:102, bitpolymul.c:77).
+ *  - "host" pointers are ordinary caller-owned memory; results stay resident in HBM inside the
+ *    context until a *_download / output pointer asks for them.
+ *  - a context may be used from one host thread at a time; two contexts may run concurrently.
+ *  - cites are relative to /root/reference/crates.
+ */
+#ifndef FLUTE_SOT_H
+#define FLUTE_SOT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOT_OK 0
+#define SOT_EINVAL -1  /* bad argument / shape mismatch */
+#define SOT_EDEVICE -2 /* HIP runtime error or no gfx950 device */
+#define SOT_ENOMEM -3
+#define SOT_ESTATE -4 /* stage called out of order (e.g. hash before encode) */
+
+#define SOT_ROLE_SENDER 0
+#define SOT_ROLE_RECEIVER 1
+
+/* QuasiCyclicConf (zappot/src/silent_ot/quasi_cyclic_encode.rs:156-233) + PprfConfig (pprf.rs:40-44) */
+typedef struct sot_conf {
+    uint64_t n;        /* requested_num_ots */
+    uint64_t scaler;   /* MultType::QuasiCyclic{scaler}; only 2 is supported (bench.rs:85) */
+    uint64_t P;        /* next_prime(max(n, 128*128)) */
+    uint64_t parts;    /* num_partitions = GGM trees */
+    uint64_t size_per; /* PPRF domain */
+    uint64_t N2;
+    uint64_t N;
+    uint64_t depth;
+    uint64_t n_blocks; /* N / 128 */
+    uint64_t n64;      /* 2 * n_blocks */
+    uint64_t cols;     /* columns of the 128 x cols rT matrix, pprf.rs:91 */
+    uint64_t base_ot_count;
+} sot_conf;
+
+typedef struct sot_ctx sot_ctx;
+
+const char *sot_last_error(void);
+/* number of usable gfx950 devices (0 if none) */
+int sot_device_count(void);
+
+/* QuasiCyclicConf::configure(num_ots, scaler, sec_param) -- quasi_cyclic_encode.rs:177-193,
+ * silent_ot/mod.rs:671-695. Pure host arithmetic (same f64 operations). */
+int sot_configure(uint64_t n, uint64_t scaler, uint64_t sec_param, sot_conf *out);
+
+/* Encoder::configure + pprf::{Sender,Receiver}::new + init_a_polynomials
+ * (silent_ot/mod.rs:148,331; quasi_cyclic_encode.rs:127-138): allocates every device buffer for one
+ * sender and one receiver instance of `n` OTs and transforms the public polynomial a once. */
+int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx **out);
+void sot_ctx_destroy(sot_ctx *ctx);
+int sot_ctx_conf(const sot_ctx *ctx, sot_conf *out);
+/* device bytes held by the context */
+uint64_t sot_ctx_device_bytes(const sot_ctx *ctx);
+/* block until all work queued by this context has finished */
+int sot_ctx_sync(sot_ctx *ctx);
+/* the hipStream_t this context launches on (for external event timing) */
+void *sot_ctx_stream(sot_ctx *ctx);
+
+/* ---- stage 1: PPRF expansion -------------------------------------------------------------- */
+/* TreeGrp flat layout (pprf.rs:752-757), group g/8 = 0 .. parts/8-1:
+ *   tg_sums [grp][keep(2)][d (depth-1)][tree(8)] Blocks,  tg_last [grp][tree(8)][4] Blocks.
+ * The Rust shim (de)serialises these into pprf::Msg::TreeGrp for mpc_channel. */
+size_t sot_treegrp_sums_blocks(const sot_conf *c);
+size_t sot_treegrp_last_blocks(const sot_conf *c);
+
+/* pprf::Sender::expand(value = delta, InterleavedTransposed) -- pprf.rs:71-281.
+ * base_ots: [tree*depth + d][2] Blocks (Array2 order, pprf.rs:67); seed: the Block the reference
+ * draws with rng.gen() at pprf.rs:96; num_threads: rayon pool size (roots depend on it, pprf.rs:115).
+ * Writes the TreeGrp payload for the peer to host memory. The expanded leaves stay in HBM. */
+int sot_sender_expand(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed, uint64_t num_threads,
+                      void *tg_sums_out, void *tg_last_out);
+/* pprf::Receiver::expand -- pprf.rs:295-560. base_ots [tree*depth + d] Blocks, choices u8 0/1 same order. */
+int sot_receiver_expand(sot_ctx *ctx, const void *base_ots, const uint8_t *choices, const void *tg_sums,
+                        const void *tg_last);
+/* pprf::Receiver::get_points(InterleavedTransposed) -- pprf.rs:563-577 (host arithmetic) */
+int sot_receiver_points(const sot_conf *c, const uint8_t *choices, uint64_t *points_out);
+/* The reference's return value of expand: Array2<Block>(128, cols), row major, i.e. the leaves
+ * after copy_out's 128x128 bit transposes (pprf.rs:790-835, util/transpose.rs:53-109). */
+int sot_download_rT(sot_ctx *ctx, int role, void *rT_out);
+
+/* ---- stage 2: QuasiCyclic encode ---------------------------------------------------------- */
+/* QuasiCyclicEncoder::dual_encode (sender, quasi_cyclic_encode.rs:29-52) /
+ * dual_encode2 with ChoiceBitPacking::True (receiver, :54-124, silent_ot/mod.rs:552-575).
+ * For the receiver `points` are the `parts` interleaved noisy positions S. */
+int sot_qc_encode(sot_ctx *ctx, int role, const uint64_t *points, uint64_t npoints);
+/* correlated_silent_send / correlated_silent_receive outputs: n Blocks (silent_ot/mod.rs:217,410) */
+int sot_download_encoded(sot_ctx *ctx, int role, void *blocks_out);
+
+/* ---- stage 3: hashes + MT bits ------------------------------------------------------------- */
+/* Sender::hash (silent_ot/mod.rs:275-287): out = n x [Block;2] */
+int sot_sender_hash(sot_ctx *ctx, const void *delta, void *msgs_out);
+/* Receiver::hash (silent_ot/mod.rs:470-482): msgs n Blocks, choices BitVec<usize,Lsb0> as ceil(n/64) u64 */
+int sot_receiver_hash(sot_ctx *ctx, void *msgs_out, uint64_t *choice_words_out);
+/* SilentMtProvider::precompute_mts bit derivation (gmw/src/mul_triple/silent_ot.rs:93-111), fused with
+ * both hashes: needs the sender AND receiver instance of this context encoded. a, b, c: ceil(n/64) u64
+ * each (MulTriples' three BitVec<usize, Lsb0>, gmw/src/mul_triple/mod.rs:30-35). Host pointers may be
+ * NULL to leave the bits on the device only. */
+int sot_mt_bits(sot_ctx *ctx, const void *delta, uint64_t *a_out, uint64_t *b_out, uint64_t *c_out);
+
+/* ---- whole-direction pipelines (random_silent_send / random_silent_receive) --------------- */
+/* silent_ot/mod.rs:193-211. msgs_out may be NULL (results stay in HBM). */
+int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed,
+                           uint64_t num_threads, void *tg_sums_out, void *tg_last_out, void *msgs_out);
+/* silent_ot/mod.rs:391-404 */
+int sot_random_silent_receive(sot_ctx *ctx, const void *base_ots, const uint8_t *choices, const void *tg_sums,
+                              const void *tg_last, void *msgs_out, uint64_t *choice_words_out);
+
+/* ---- fixture-level entry points ------------------------------------------------------------- */
+/* util/transpose.rs:9-14 transpose_128 on `ntiles` independent 128x128 bit tiles (host in/out) */
+int sot_transpose128(int device, const void *tiles_in, void *tiles_out, uint64_t ntiles);
+/* AES-128 ECB of host blocks with an arbitrary key (crate aes 0.8.3, used for KATs) */
+int sot_aes128_encrypt(int device, const void *key16, const void *in, void *out, uint64_t nblocks);
+/* AesHash::cr_hash_slice_mut (util/aes_hash.rs:47-55) on host blocks */
+int sot_cr_hash(int device, const void *in, void *out, uint64_t nblocks);
+/* QuasiCyclicEncoder::dual_encode / dual_encode2(packed) on a caller-supplied rT
+ * (Array2<Block>(128, cols), host) -- quasi_cyclic_encode.rs:29-124. Un-transposes rT on the device and
+ * runs the same encode kernels; result (n Blocks) is written to blocks_out and kept in HBM for the hashes. */
+int sot_qc_dual_encode_host(sot_ctx *ctx, int role, const void *rT, const uint64_t *points, uint64_t npoints,
+                            void *blocks_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

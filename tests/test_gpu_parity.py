@@ -1,0 +1,176 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs. Integer/bit work: the bar is bit-exact equality."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flute_amd
+    if flute_amd.device_count() < 1:
+        pytest.fail("no gfx950 device visible: GPU tests need an MI355X")
+    return flute_amd
+
+
+def _inputs(orc, n, seed):
+    conf = orc.configure(n)
+    rng = np.random.default_rng(seed)
+    msg2, msg, choices = orc.fake_base(conf, rng)
+    delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    prg = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    return conf, msg2, msg, choices, delta, prg
+
+
+# ------------------------------------------------------------------ fixtures-level entry points
+def test_aes_kat_on_gpu(fa, orc):
+    import ctypes as C
+    L = fa.load_library()
+    key = np.frombuffer(bytes(range(16)), dtype=np.uint8).copy()
+    pt = np.frombuffer(bytes.fromhex("00112233445566778899aabbccddeeff"), dtype=np.uint8).copy()
+    out = np.zeros(16, dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.sot_aes128_encrypt(0, p(key), p(pt), p(out), 1) == 0
+    assert out.tobytes().hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"  # FIPS-197 C.1
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 2 ** 64, size=(5000, 2), dtype=np.uint64)
+    k2 = rng.integers(0, 256, 16, dtype=np.uint8)
+    o2 = np.zeros_like(data)
+    assert L.sot_aes128_encrypt(0, p(k2), p(data), p(o2), 5000) == 0
+    assert o2.tobytes() == orc.aes128_encrypt(k2.tobytes(), data.tobytes())
+    o3 = np.zeros_like(data)
+    assert L.sot_cr_hash(0, p(data), p(o3), 5000) == 0
+    assert np.array_equal(o3, orc.cr_hash(data))
+
+
+def test_transpose128_on_gpu(fa, orc):
+    import ctypes as C
+    L = fa.load_library()
+    rng = np.random.default_rng(1)
+    tiles = rng.integers(0, 2 ** 64, size=(37, 128, 2), dtype=np.uint64)
+    out = np.zeros_like(tiles)
+    assert L.sot_transpose128(0, tiles.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 37) == 0
+    for i in range(37):
+        assert np.array_equal(out[i], orc.transpose_128(tiles[i])), i
+    # reference KAT (util/transpose.rs:168-210) embedded in a 128x128 tile: column 0 set -> row 0 all ones
+    t = np.zeros((1, 128, 2), dtype=np.uint64)
+    t[0, :, 0] = 1
+    o = np.zeros_like(t)
+    assert L.sot_transpose128(0, t.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), 1) == 0
+    assert o[0, 0, 0] == M64 and o[0, 0, 1] == M64 and not o[0, 1:].any()
+
+
+# ------------------------------------------------------------------ stage by stage
+@pytest.mark.parametrize("n,T,seed", [(1000, 2, 42), (1000, 1, 7), (40000, 4, 3), (1 << 16, 5, 11)])
+def test_pipeline_stages_match_oracle(fa, orc, n, T, seed):
+    conf, msg2, msg, choices, delta, prg = _inputs(orc, n, seed)
+    eng = fa.Engine(n)
+    try:
+        assert eng.conf.c.as_dict() == conf.as_dict()
+        # --- PPRF sender
+        o_rT_s, o_sums, o_last = orc.pprf_sender_expand(conf, msg2, delta, prg, T)
+        sums, last = eng.sender_expand(msg2, delta, prg, T)
+        assert np.array_equal(sums, o_sums), "TreeGrp sums"
+        assert np.array_equal(last, o_last), "TreeGrp last_ots"
+        assert np.array_equal(eng.download_rT(0), o_rT_s), "sender rT"
+        # --- PPRF receiver
+        o_rT_r = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
+        eng.receiver_expand(msg, choices, sums, last)
+        assert np.array_equal(eng.download_rT(1), o_rT_r), "receiver rT"
+        pts = eng.points(choices)
+        assert np.array_equal(pts, orc.pprf_points(conf, choices))
+        # --- QC encode
+        o_B = orc.qc_dual_encode(conf, o_rT_s)
+        eng.qc_encode(0)
+        B = eng.download_encoded(0)
+        assert np.array_equal(B, o_B), "sender dual_encode"
+        o_A, _ = orc.qc_dual_encode2(conf, o_rT_r, pts, packed=True)
+        eng.qc_encode(1, pts)
+        A = eng.download_encoded(1)
+        assert np.array_equal(A, o_A), "receiver dual_encode2"
+        # --- hashes
+        o_msgs = orc.sender_hash(delta, o_B)
+        assert np.array_equal(eng.sender_hash(delta), o_msgs)
+        o_rmsgs, o_ch = orc.receiver_hash(o_A)
+        rmsgs, ch = eng.receiver_hash()
+        assert np.array_equal(rmsgs, o_rmsgs) and np.array_equal(ch, o_ch)
+        # --- MT bits (this context's sender and receiver instance as one party's two directions)
+        oa, ob, oc = orc.mt_bits(o_msgs.reshape(-1, 2), o_rmsgs, o_ch)
+        a, b, c = eng.mt_bits(delta)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob) and np.array_equal(c, oc)
+        # --- reference properties on the GPU outputs (check_random, silent_ot/mod.rs:779-795)
+        sel = np.unpackbits(ch.view(np.uint8), bitorder="little")[:n].astype(np.int64)
+        msgs = eng.sender_hash(delta)
+        chosen = msgs[np.arange(n), sel]
+        other = msgs[np.arange(n), 1 - sel]
+        assert np.array_equal(chosen, rmsgs)
+        assert not (other == rmsgs).all(axis=1).any()
+    finally:
+        eng.close()
+
+
+def test_dual_encode_from_host_rT(fa, orc):
+    n = 5000
+    conf = orc.configure(n)
+    rng = np.random.default_rng(9)
+    rT = rng.integers(0, 2 ** 64, size=(128, int(conf.cols), 2), dtype=np.uint64)
+    eng = fa.Engine(n)
+    try:
+        assert np.array_equal(eng.qc_dual_encode_host(0, rT), orc.qc_dual_encode(conf, rT))
+        S = np.sort(rng.choice(int(conf.N2), size=int(conf.parts), replace=False)).astype(np.uint64)
+        want, _ = orc.qc_dual_encode2(conf, rT, S, packed=True)
+        assert np.array_equal(eng.qc_dual_encode_host(1, rT, S), want)
+    finally:
+        eng.close()
+
+
+def test_mirror_classes_random_ot(fa, orc):
+    """random_silent_ot of the reference (silent_ot/mod.rs:874-904) through the mirrored Sender/Receiver."""
+    n, T = 1000, 2
+    eng = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(42)
+        msg2, msg, choices = fa.fake_base(eng.conf, rng)
+        delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        snd = fa.Sender.new_with_silent_base_ots(eng, msg2, T)
+        rcv = fa.Receiver.new_with_silent_base_ots(eng, msg, choices, T)
+        s_out = snd.random_silent_send(delta, seed)
+        r_out, ch = rcv.random_silent_receive(snd.tree_groups)
+        sel = np.unpackbits(ch.view(np.uint8), bitorder="little")[:n].astype(np.int64)
+        assert 0 < sel.sum() < n
+        assert np.array_equal(s_out[np.arange(n), sel], r_out)
+        assert not (s_out[np.arange(n), 1 - sel] == r_out).all(axis=1).any()
+    finally:
+        eng.close()
+
+
+def test_two_party_mt_relation(fa, orc):
+    """c1 ^ c2 == (a1 ^ a2) & (b1 ^ b2) (gmw/src/mul_triple/silent_ot.rs:166-168) with two providers."""
+    n, T = 3000, 3
+    e0, e1 = fa.Engine(n), fa.Engine(n)
+    try:
+        rng = np.random.default_rng(77)
+        x = fa.fake_base(e0.conf, rng)  # direction X: party 0 sends, party 1 receives
+        y = fa.fake_base(e0.conf, rng)  # direction Y: party 1 sends, party 0 receives
+        p0 = fa.SilentMtProvider(e0, x[0], y[1], y[2], T)
+        p1 = fa.SilentMtProvider(e1, y[0], x[1], x[2], T)
+        d0, d1, s0, s1 = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+        tg0 = p0.send_phase(d0, s0)
+        tg1 = p1.send_phase(d1, s1)
+        p0.receive_phase(tg1)
+        p1.receive_phase(tg0)
+        m0, m1 = p0.request_mts(1000), p1.request_mts(1000)
+        assert p0.mts_available() == n - 1000
+        bits = fa.MulTriples._bits
+        a = bits(m0.a, 1000) ^ bits(m1.a, 1000)
+        b = bits(m0.b, 1000) ^ bits(m1.b, 1000)
+        c = bits(m0.c, 1000) ^ bits(m1.c, 1000)
+        assert np.array_equal(c, a & b)
+        assert 0 < a.sum() < 1000 and 0 < b.sum() < 1000
+    finally:
+        e0.close()
+        e1.close()
