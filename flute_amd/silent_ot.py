@@ -49,9 +49,6 @@ class QuasiCyclicConf:
         check(load_library().sot_configure(num_ots, scaler, sec_param, C.byref(c)))
         return QuasiCyclicConf(c)
 
-    def base_ot_count(self):
-        return self.depth * self.parts
-
     def treegrp_shapes(self):
         grp = self.parts // 8
         return (grp, 2, self.depth - 1, 8, 2), (grp, 8, 4, 2)
@@ -87,7 +84,7 @@ def sample_base_choice_bits(conf, rng):
 
 def fake_base(conf, rng):
     """pprf.rs:858-873 test helper: fabricated base OTs (sender pairs, receiver picks, choices)."""
-    cnt = conf.base_ot_count()
+    cnt = conf.base_ot_count
     msg2 = rng.integers(0, 2 ** 64, size=(cnt, 2, 2), dtype=np.uint64)
     choices = sample_base_choice_bits(conf, rng)
     msg = msg2[np.arange(cnt), choices.reshape(-1).astype(np.int64)].copy()
@@ -133,7 +130,7 @@ class Engine:
     def sender_expand(self, base_ots, delta, seed, num_threads):
         cf = self.conf
         base_ots = np.ascontiguousarray(base_ots, dtype=np.uint64)
-        if base_ots.shape != (cf.base_ot_count(), 2, 2):
+        if base_ots.shape != (cf.base_ot_count, 2, 2):
             raise ValueError("Wrong number of silent base ots")  # mod.rs:171-175
         s_shape, l_shape = cf.treegrp_shapes()
         sums = np.zeros(s_shape, dtype=np.uint64)
@@ -146,7 +143,7 @@ class Engine:
         cf = self.conf
         base_ots = np.ascontiguousarray(base_ots, dtype=np.uint64)
         choices = np.ascontiguousarray(choices, dtype=np.uint8)
-        if base_ots.shape != (cf.base_ot_count(), 2) or choices.size != cf.base_ot_count():
+        if base_ots.shape != (cf.base_ot_count, 2) or choices.size != cf.base_ot_count:
             raise ValueError("Wrong number of silent base ots / choices")
         s_shape, l_shape = cf.treegrp_shapes()
         tg_sums = np.ascontiguousarray(tg_sums, dtype=np.uint64)
@@ -224,7 +221,7 @@ class Sender:
         self.engine = engine
         self.enc = engine.conf
         self.base_ots = np.ascontiguousarray(silent_base_ots, dtype=np.uint64)
-        if self.base_ots.shape[0] != self.enc.base_ot_count():
+        if self.base_ots.shape[0] != self.enc.base_ot_count:
             raise ValueError("Wrong number of silent base ots")
         self.num_threads = num_threads
         self.tree_groups = None
@@ -256,7 +253,7 @@ class Receiver:
         self.enc = engine.conf
         self.base_ots = np.ascontiguousarray(silent_base_ots, dtype=np.uint64)
         self.choices = np.ascontiguousarray(silent_base_choices, dtype=np.uint8)
-        if self.base_ots.shape[0] != self.enc.base_ot_count():
+        if self.base_ots.shape[0] != self.enc.base_ot_count:
             raise ValueError("Wrong number of silent base ots")
         self.num_threads = num_threads
         self.S = engine.points(self.choices)  # mod.rs:368
