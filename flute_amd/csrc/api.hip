@@ -28,6 +28,73 @@ extern "C" int sot_device_count(void) {
     return ok;
 }
 
+// ---------------------------------------------------------------- per-kernel event timing
+const char *const SOT_KID_NAMES[KID_COUNT] = {
+    "k_roots",       "k_ggm_level",     "k_ggm_leaf", "k_sender_treegrp", "k_recv_init",  "k_recv_fix",
+    "k_recv_last",   "k_transpose_tiles", "k_sender_hash", "k_receiver_hash", "k_mt_bits",  "k_clear_lsb",
+    "k_qc_load",     "k_conv_phase16",  "k_qc_expand", "k_fft_level",     "k_fft_low_mul", "k_ifft_level",
+    "k_qc_unpack",   "k_conv_phase32",  "k_qc_store",  "k_qc_final"};
+
+static hipEvent_t prof_event(sot_ctx *c) {
+    if (!c->prof_free.empty()) {
+        hipEvent_t e = c->prof_free.back();
+        c->prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(sot_ctx *c, int id) {
+    prof_rec r;
+    r.id = id;
+    r.a = prof_event(c);
+    r.b = prof_event(c);
+    (void)hipEventRecord(r.a, c->stream);
+    c->prof_pending.push_back(r);
+}
+void prof_end(sot_ctx *c, int id) {
+    (void)id;
+    (void)hipEventRecord(c->prof_pending.back().b, c->stream);
+    if (c->prof_pending.size() > 4096) prof_resolve(c);
+}
+void prof_resolve(sot_ctx *c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->prof_ms[r.id] += ms;
+            c->prof_n[r.id] += 1;
+        }
+        c->prof_free.push_back(r.a);
+        c->prof_free.push_back(r.b);
+    }
+    c->prof_pending.clear();
+}
+
+extern "C" int sot_prof_enable(sot_ctx *c, int on) {
+    if (!c) return SOT_EINVAL;
+    prof_resolve(c);
+    c->prof = on != 0;
+    return SOT_OK;
+}
+extern "C" int sot_prof_reset(sot_ctx *c) {
+    if (!c) return SOT_EINVAL;
+    prof_resolve(c);
+    for (int i = 0; i < KID_COUNT; i++) c->prof_ms[i] = 0, c->prof_n[i] = 0;
+    return SOT_OK;
+}
+extern "C" int sot_prof_kernels(void) { return KID_COUNT; }
+extern "C" const char *sot_prof_name(int id) { return id >= 0 && id < KID_COUNT ? SOT_KID_NAMES[id] : ""; }
+extern "C" int sot_prof_read(sot_ctx *c, int id, double *total_ms, uint64_t *launches) {
+    if (!c || id < 0 || id >= KID_COUNT) return SOT_EINVAL;
+    prof_resolve(c);
+    if (total_ms) *total_ms = c->prof_ms[id];
+    if (launches) *launches = c->prof_n[id];
+    return SOT_OK;
+}
+
 // ---------------------------------------------------------------- configuration
 static int is_prime(uint64_t x) {
     if (x < 2) return 0;
@@ -115,6 +182,8 @@ extern "C" void sot_ctx_destroy(sot_ctx *c) {
                     c->d_points};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    prof_resolve(c);
+    for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -349,16 +349,16 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
         dim3 grid(gx, nsets);
         blk_t *lsum = c->sums + (uint64_t)d * nsets * 16;
         if (d + 1 < depth) {
-            hipLaunchKernelGGL(k_ggm_level<false>, grid, dim3(GGM_BLOCK), 0, c->stream, cur, nxt, d, nsets,
+            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_level<false>, grid, dim3(GGM_BLOCK), cur, nxt, d, nsets,
                                c->conf.cols, lsum);
             if (receiver)
-                hipLaunchKernelGGL(k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), 0, c->stream, c->d_base,
+                SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), c->d_base,
                                    c->d_choices, c->d_tg_sums, lsum, (uint32_t)c->conf.parts, depth, d, nxt);
             blk_t *t = cur;
             cur = nxt;
             nxt = t;
         } else {
-            hipLaunchKernelGGL(k_ggm_level<true>, grid, dim3(GGM_BLOCK), 0, c->stream, cur, V, d, nsets, c->conf.cols,
+            SOT_LAUNCH(c, KID_GGM_LEAF, k_ggm_level<true>, grid, dim3(GGM_BLOCK), cur, V, d, nsets, c->conf.cols,
                                lsum);
         }
     }
@@ -395,12 +395,12 @@ int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const
     SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 32, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
     blk_t *V = c->role[SOT_ROLE_SENDER].V;
-    hipLaunchKernelGGL(k_roots, dim3((cf.parts + 127) / 128), dim3(128), 0, c->stream, c->d_rks, (uint32_t)T,
+    SOT_LAUNCH(c, KID_ROOTS, k_roots, dim3((cf.parts + 127) / 128), dim3(128), c->d_rks, (uint32_t)T,
                        (uint32_t)cf.parts, c->lvl_a);
     SOT_TRY(launch_levels(c, false, V));
     blk_t d;
     memcpy(&d, delta, 16);
-    hipLaunchKernelGGL(k_sender_treegrp, dim3((cf.parts + 127) / 128), dim3(128), 0, c->stream, c->sums, c->d_base, d,
+    SOT_LAUNCH(c, KID_SENDER_TG, k_sender_treegrp, dim3((cf.parts + 127) / 128), dim3(128), c->sums, c->d_base, d,
                        (uint32_t)cf.parts, (uint32_t)cf.depth, c->d_tg_sums, c->d_tg_last);
     SOT_HIP(hipGetLastError());
     if (tg_sums_out)
@@ -431,10 +431,10 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
     SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
     blk_t *V = c->role[SOT_ROLE_RECEIVER].V;
     dim3 gt((cf.parts + 127) / 128), bt(128);
-    hipLaunchKernelGGL(k_recv_init, gt, bt, 0, c->stream, c->d_base, c->d_choices, c->d_tg_sums, (uint32_t)cf.parts,
+    SOT_LAUNCH(c, KID_RECV_INIT, k_recv_init, gt, bt, c->d_base, c->d_choices, c->d_tg_sums, (uint32_t)cf.parts,
                        (uint32_t)cf.depth, c->lvl_b);
     SOT_TRY(launch_levels(c, true, V));
-    hipLaunchKernelGGL(k_recv_last, gt, bt, 0, c->stream, c->d_base, c->d_choices, c->d_tg_last,
+    SOT_LAUNCH(c, KID_RECV_LAST, k_recv_last, gt, bt, c->d_base, c->d_choices, c->d_tg_last,
                        c->sums + (cf.depth - 1) * c->nsets * 16, (uint32_t)cf.parts, (uint32_t)cf.depth, cf.cols, V);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
@@ -462,7 +462,7 @@ int ggm_download_rT(sot_ctx *c, int role, void *out) {
     SOT_HIP(hipSetDevice(c->device));
     uint64_t bytes = 128 * cf.cols * 16;
     SOT_TRY(ensure_tmp(c, bytes));
-    hipLaunchKernelGGL(k_transpose_tiles, dim3(grid_for(cf.cols, 1, 8192)), dim3(128), 0, c->stream, c->role[role].V,
+    SOT_LAUNCH(c, KID_TRANSPOSE, k_transpose_tiles, dim3(grid_for(cf.cols, 1, 8192)), dim3(128), c->role[role].V,
                        (uint64_t)1, (uint64_t)128, (blk_t *)c->d_tmp, cf.cols, (uint64_t)1, cf.cols);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipMemcpyAsync(out, c->d_tmp, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -496,7 +496,7 @@ int hash_sender(sot_ctx *c, const void *delta, void *msgs_out) {
     SOT_TRY(ensure_tmp(c, cf.n * 32));
     blk_t d;
     memcpy(&d, delta, 16);
-    hipLaunchKernelGGL(k_sender_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream,
+    SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256),
                        c->role[SOT_ROLE_SENDER].enc, d, cf.n, (blk_t *)c->d_tmp);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 32, hipMemcpyDeviceToHost, c->stream));
@@ -513,7 +513,7 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
     SOT_HIP(hipSetDevice(c->device));
     SOT_TRY(ensure_tmp(c, cf.n * 32));
     uint64_t nw = (cf.n + 63) / 64;
-    hipLaunchKernelGGL(k_receiver_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream,
+    SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256),
                        c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_mt);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -532,7 +532,7 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
     uint64_t nw = (cf.n + 63) / 64;
     blk_t d;
     memcpy(&d, delta, 16);
-    hipLaunchKernelGGL(k_mt_bits, dim3(grid_for(cf.n, 256, 2048)), dim3(256), 0, c->stream, c->role[0].enc,
+    SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(cf.n, 256, 2048)), dim3(256), c->role[0].enc,
                        c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
     SOT_HIP(hipGetLastError());
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));

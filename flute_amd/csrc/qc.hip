@@ -613,13 +613,13 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const unsigned grid = gridn(total, 256, 1u << 20);
     if (!inverse) {
         for (size_t i = 0; i < ph.size(); i++) {
-            hipLaunchKernelGGL(k_conv_phase<NP>, dim3(grid), dim3(256), 0, c->stream, bufs[cur], bufs[cur ^ 1], nwords,
+            SOT_LAUNCH(c, NP == 16 ? KID_CONV16 : KID_CONV32, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
                                ph[i].chunk, ph[i].pw, ph[i].half, 0);
             cur ^= 1;
         }
     } else {
         for (size_t i = ph.size(); i-- > 0;) {
-            hipLaunchKernelGGL(k_conv_phase<NP>, dim3(grid), dim3(256), 0, c->stream, bufs[cur], bufs[cur ^ 1], nwords,
+            SOT_LAUNCH(c, NP == 16 ? KID_CONV16 : KID_CONV32, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
                                ph[i].chunk, ph[i].pw, ph[i].half, 1);
             cur ^= 1;
         }
@@ -632,11 +632,11 @@ static int forward_to_D(sot_ctx *c, int xcur) {
     const qc_geom &g = c->g;
     uint32_t *xb[2] = {c->X0, c->X1};
     xcur = run_conversion<16>(c, xb, xcur, g.ell - 1, g.nw_in, false);
-    hipLaunchKernelGGL(k_qc_expand, dim3(gridn(g.nw_in * ROWS, 256, 1u << 20)), dim3(256), 0, c->stream, xb[xcur],
+    SOT_LAUNCH(c, KID_QC_EXPAND, k_qc_expand, dim3(gridn(g.nw_in * ROWS, 256, 1u << 20)), dim3(256), xb[xcur],
                        c->D0, g.nw_in);
     const uint64_t npairs = g.nw / 2;
     for (int i = (int)g.ell - 2; i >= 5; i--)
-        hipLaunchKernelGGL(k_fft_level<false>, dim3(gridn(npairs, 4)), dim3(256), 0, c->stream, c->D0, npairs,
+        SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_level<false>, dim3(gridn(npairs, 4)), dim3(256), c->D0, npairs,
                            (uint32_t)(i - 5), c->TW, c->TWC);
     SOT_HIP(hipGetLastError());
     return SOT_OK;
@@ -736,24 +736,24 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     const uint64_t nV = cf.cols * 128;
     if (role == SOT_ROLE_RECEIVER) {
         SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), 0, c->stream, V, nV);
-        hipLaunchKernelGGL(k_set_points, dim3((npoints + 127) / 128), dim3(128), 0, c->stream, V, c->d_points,
+        SOT_LAUNCH(c, KID_CLEAR_LSB, k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), V, nV);
+        SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), V, c->d_points,
                            (uint32_t)npoints, nV);
     }
-    hipLaunchKernelGGL(k_qc_load, dim3(gridn(g.nw_in, 4)), dim3(256), 0, c->stream, V + nb128, nb128, cf.P, g.lo_bits,
+    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw_in, 4)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
                        g.nw_in, c->X0);
     SOT_TRY(forward_to_D(c, 0));
-    hipLaunchKernelGGL(k_fft_low<1>, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, c->D0, g.nw, c->TW, c->TWC,
+    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(gridn(g.nw, 4)), dim3(256), c->D0, g.nw, c->TW, c->TWC,
                        c->Amat);
     const uint64_t npairs = g.nw / 2;
     for (int i = 5; i < (int)g.ell; i++)
-        hipLaunchKernelGGL(k_fft_level<true>, dim3(gridn(npairs, 4)), dim3(256), 0, c->stream, c->D0, npairs,
+        SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_level<true>, dim3(gridn(npairs, 4)), dim3(256), c->D0, npairs,
                            (uint32_t)(i - 5), c->TW, c->TWC);
-    hipLaunchKernelGGL(k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), 0, c->stream, c->D0, g.nw);
+    SOT_LAUNCH(c, KID_QC_UNPACK, k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), c->D0, g.nw);
     uint32_t *db[2] = {c->D0, c->D1};
     int cur = run_conversion<32>(c, db, 0, g.ell, g.nw, true);
-    hipLaunchKernelGGL(k_qc_store, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, db[cur], g.nw, c->T);
-    hipLaunchKernelGGL(k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), 0, c->stream, V, nb128, cf.P, g.S, g.tail,
+    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, 4)), dim3(256), db[cur], g.nw, c->T);
+    SOT_LAUNCH(c, KID_QC_FINAL, k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), V, nb128, cf.P, g.S, g.tail,
                        cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));

@@ -44,6 +44,39 @@ struct qc_geom {
     uint64_t nw;       // words per plane of the 32-plane domain = L / 32
 };
 
+// kernel ids for the optional per-kernel HIP-event timing (sot_prof_*)
+enum sot_kid {
+    KID_ROOTS = 0,
+    KID_GGM_LEVEL,
+    KID_GGM_LEAF,
+    KID_SENDER_TG,
+    KID_RECV_INIT,
+    KID_RECV_FIX,
+    KID_RECV_LAST,
+    KID_TRANSPOSE,
+    KID_SENDER_HASH,
+    KID_RECEIVER_HASH,
+    KID_MT_BITS,
+    KID_CLEAR_LSB,
+    KID_QC_LOAD,
+    KID_CONV16,
+    KID_QC_EXPAND,
+    KID_FFT_LEVEL,
+    KID_FFT_LOW_MUL,
+    KID_IFFT_LEVEL,
+    KID_QC_UNPACK,
+    KID_CONV32,
+    KID_QC_STORE,
+    KID_QC_FINAL,
+    KID_COUNT
+};
+extern const char *const SOT_KID_NAMES[KID_COUNT];
+
+struct prof_rec {
+    int id;
+    hipEvent_t a, b;
+};
+
 struct role_state {
     blk_t *V = nullptr;        // leaves, interleaved order, cols*128 Blocks (rT before the bit transposes)
     blk_t *enc = nullptr;      // encoded output, n Blocks (B for the sender, A for the receiver)
@@ -81,7 +114,23 @@ struct sot_ctx {
     uint64_t *d_mt = nullptr;  // a | b | c words
     void *d_tmp = nullptr;     // download staging
     uint64_t tmp_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<prof_rec> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+    double prof_ms[KID_COUNT] = {0};
+    uint64_t prof_n[KID_COUNT] = {0};
 };
+
+void prof_begin(sot_ctx *c, int id);
+void prof_end(sot_ctx *c, int id);
+void prof_resolve(sot_ctx *c);
+#define SOT_LAUNCH(c, id, kernel, grid, block, ...)                              \
+    do {                                                                         \
+        if ((c)->prof) prof_begin((c), (id));                                    \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (c)->stream, __VA_ARGS__);    \
+        if ((c)->prof) prof_end((c), (id));                                      \
+    } while (0)
 
 // ---- ggm.hip
 int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const void *seed, uint64_t T,

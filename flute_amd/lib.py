@@ -26,7 +26,8 @@ EXPORTS = [
     "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
     "sot_sender_expand", "sot_receiver_expand", "sot_receiver_points", "sot_download_rT", "sot_qc_encode",
     "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_random_silent_send",
-    "sot_random_silent_receive", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
+    "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
+    "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
 ]
 
 
@@ -66,6 +67,12 @@ def load_library():
     L.sot_mt_bits.argtypes = [P, P, P, P, P]
     L.sot_random_silent_send.argtypes = [P, P, P, P, u64, P, P, P]
     L.sot_random_silent_receive.argtypes = [P, P, P, P, P, P, P]
+    L.sot_prof_enable.argtypes = [P, i32]
+    L.sot_prof_reset.argtypes = [P]
+    L.sot_prof_kernels.restype = i32
+    L.sot_prof_name.argtypes = [i32]
+    L.sot_prof_name.restype = C.c_char_p
+    L.sot_prof_read.argtypes = [P, i32, C.POINTER(C.c_double), C.POINTER(u64)]
     L.sot_transpose128.argtypes = [i32, P, P, u64]
     L.sot_aes128_encrypt.argtypes = [i32, P, P, P, u64]
     L.sot_cr_hash.argtypes = [i32, P, P, u64]

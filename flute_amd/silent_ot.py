@@ -126,6 +126,23 @@ class Engine:
     def sync(self):
         check(self.lib.sot_ctx_sync(self.h))
 
+    # ---- per-kernel HIP-event timing (sot_prof_*)
+    def prof_enable(self, on=True):
+        check(self.lib.sot_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.sot_prof_reset(self.h))
+
+    def prof_read(self):
+        """{kernel name: (total device ms, launches)} for kernels that ran."""
+        out = {}
+        for i in range(self.lib.sot_prof_kernels()):
+            ms, cnt = C.c_double(), C.c_uint64()
+            check(self.lib.sot_prof_read(self.h, i, C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[self.lib.sot_prof_name(i).decode()] = (ms.value, int(cnt.value))
+        return out
+
     # ---- stage-level calls (shapes checked here: the kernels trust them)
     def sender_expand(self, base_ots, delta, seed, num_threads):
         cf = self.conf

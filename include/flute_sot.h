@@ -124,6 +124,15 @@ int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta
 int sot_random_silent_receive(sot_ctx *ctx, const void *base_ots, const uint8_t *choices, const void *tg_sums,
                               const void *tg_last, void *msgs_out, uint64_t *choice_words_out);
 
+/* ---- measurement hooks (no counterpart in the reference; bench.rs:206-219 only wall-clocks phases) ------ */
+/* Per-kernel HIP-event timing on the context's stream. While enabled every kernel launch is bracketed
+ * by two events; sot_prof_read synchronises and returns the accumulated device time and launch count. */
+int sot_prof_enable(sot_ctx *ctx, int on);
+int sot_prof_reset(sot_ctx *ctx);
+int sot_prof_kernels(void);
+const char *sot_prof_name(int kernel_id);
+int sot_prof_read(sot_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches);
+
 /* ---- fixture-level entry points ------------------------------------------------------------- */
 /* util/transpose.rs:9-14 transpose_128 on `ntiles` independent 128x128 bit tiles (host in/out) */
 int sot_transpose128(int device, const void *tiles_in, void *tiles_out, uint64_t ntiles);
