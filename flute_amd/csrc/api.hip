@@ -33,7 +33,7 @@ const char *const SOT_KID_NAMES[KID_COUNT] = {
     "k_roots",       "k_ggm_level",     "k_ggm_leaf", "k_sender_treegrp", "k_recv_init",  "k_recv_fix",
     "k_recv_last",   "k_transpose_tiles", "k_sender_hash", "k_receiver_hash", "k_mt_bits",  "k_clear_lsb",
     "k_qc_load",     "k_conv_phase16",  "k_qc_expand", "k_fft_level",     "k_fft_low_mul", "k_ifft_level",
-    "k_qc_unpack",   "k_conv_phase32",  "k_qc_store",  "k_qc_final"};
+    "k_qc_unpack",   "k_conv_phase32",  "k_qc_store",  "k_qc_final", "k_conv_tile16", "k_conv_tile32"};
 
 static hipEvent_t prof_event(sot_ctx *c) {
     if (!c->prof_free.empty()) {

@@ -32,6 +32,8 @@ static __device__ const uint32_t d_MPOS[4 * 8 * 8] = {
 
 // ------------------------------------------------------------------------------------------------
 // helpers
+// a ^ (b & c) in one VALU op (gfx950 v_bitop3_b32, truth table 0xF0 ^ (0xCC & 0xAA))
+#define XAND(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x78)
 // 32x32 bit transpose, LSB first: on return a[i] bit p == (old a[p]) bit i
 __device__ __forceinline__ void transpose32(uint32_t a[32]) {
     uint32_t m = 0x0000FFFFu;
@@ -178,6 +180,126 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2b: all conversion phases whose chunk fits a tile of 2^tb (<= 2^16) elements, fused in LDS, in place.
+// Tile = 2^(tb-5) words x 16 rows of one plane (128 KiB at tb = 16). Each phase is split in the two
+// hazard-free steps of the Taylor expansion at y = x^q + x on a chunk [lo | H]:
+//   fold : H[j] ^= H[j + D]      (j < pw, D = half - pw)        -- top pw entries of H onto its bottom
+//   shift: lo[pw + j] ^= H[j]    (j < D)
+// forward = fold then shift, inverse = shift then fold.
+struct conv_phases {
+    uint8_t n;
+    uint8_t lchunk[48], lpw[48];  // log2(chunk), log2(pw); half = chunk / 2
+};
+#define CT_ROWS 16
+#define CT_THREADS 1024
+
+__device__ __forceinline__ void ct_fold(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
+    const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
+    const uint32_t nchunks = tile_words >> (lchunk - 5);
+    if (lpw >= 5) {
+        const uint32_t pw_w = 1u << (lpw - 5);
+        const uint32_t items = nchunks * pw_w * CT_ROWS;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t c = wi >> (lpw - 5), d = wi & (pw_w - 1);
+            uint32_t base = c * chunk_w + half_w;
+            lds[(base + d) * CT_ROWS + r] ^= lds[(base + half_w - pw_w + d) * CT_ROWS + r];
+        }
+    } else {
+        const uint32_t pw = 1u << lpw;
+        const uint32_t items = nchunks * CT_ROWS;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & (CT_ROWS - 1), c = it / CT_ROWS;
+            uint32_t base = c * chunk_w + half_w;
+            lds[base * CT_ROWS + r] ^= lds[(base + half_w - 1) * CT_ROWS + r] >> (32 - pw);
+        }
+    }
+}
+
+__device__ __forceinline__ void ct_shift(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
+    const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
+    const uint32_t items = (tile_words >> 1) * CT_ROWS;
+    if (lpw >= 5) {
+        const uint32_t pw_w = 1u << (lpw - 5);
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
+            if (d >= pw_w) {
+                uint32_t base = c * chunk_w;
+                lds[(base + d) * CT_ROWS + r] ^= lds[(base + half_w + d - pw_w) * CT_ROWS + r];
+            }
+        }
+    } else {
+        const uint32_t pw = 1u << lpw;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
+            uint32_t base = c * chunk_w;
+            uint32_t h = lds[(base + half_w + d) * CT_ROWS + r] << pw;
+            if (d) h |= lds[(base + half_w + d - 1) * CT_ROWS + r] >> (32 - pw);
+            lds[(base + d) * CT_ROWS + r] ^= h;
+        }
+    }
+}
+
+// chunk <= 32: every chunk lives inside one word; combined formula on the word itself
+__device__ __forceinline__ void ct_intraword(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw,
+                                             bool inverse) {
+    const uint32_t chunk = 1u << lchunk, pw = 1u << lpw, half = chunk >> 1, D = half - pw;
+    uint32_t m1 = range_mask(half, half + pw) | range_mask(pw, half);
+    uint32_t m2 = inverse ? 0u : range_mask(pw, 2 * pw);
+    for (uint32_t s = chunk; s < 32; s <<= 1) {
+        m1 |= m1 << s;
+        m2 |= m2 << s;
+    }
+    const uint32_t items = tile_words * CT_ROWS;
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        uint32_t v = lds[it];
+        uint32_t o = v ^ ((v >> D) & m1);
+        if (2 * D < 32) o ^= (v >> (2 * D)) & m2;
+        lds[it] = o;
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(CT_THREADS)
+    k_conv_tile(uint32_t *__restrict__ D, uint32_t tb, conv_phases ph, int inverse) {
+    __shared__ uint32_t lds[2048 * CT_ROWS];
+    const uint32_t tile_words = 1u << (tb - 5);
+    // blockIdx.x = ((tile * NP) + plane) * 8 + rowgrp
+    const uint32_t rowgrp = blockIdx.x & 7;
+    const uint32_t plane = (blockIdx.x >> 3) % NP;
+    const uint64_t tile = (blockIdx.x >> 3) / NP;
+    uint32_t *g = D + (tile * tile_words * NP + plane) * ROWS + rowgrp * CT_ROWS;
+    const uint32_t items = tile_words * CT_ROWS;
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        uint32_t r = it & (CT_ROWS - 1), wl = it / CT_ROWS;
+        lds[it] = g[(uint64_t)wl * NP * ROWS + r];
+    }
+    __syncthreads();
+    for (int q = 0; q < ph.n; q++) {
+        const int i = inverse ? ph.n - 1 - q : q;
+        const uint32_t lchunk = ph.lchunk[i], lpw = ph.lpw[i];
+        if (lchunk <= 5) {
+            ct_intraword(lds, tile_words, lchunk, lpw, inverse);
+        } else if (!inverse) {
+            ct_fold(lds, tile_words, lchunk, lpw);
+            __syncthreads();
+            ct_shift(lds, tile_words, lchunk, lpw);
+        } else {
+            ct_shift(lds, tile_words, lchunk, lpw);
+            __syncthreads();
+            ct_fold(lds, tile_words, lchunk, lpw);
+        }
+        __syncthreads();
+    }
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        uint32_t r = it & (CT_ROWS - 1), wl = it / CT_ROWS;
+        g[(uint64_t)wl * NP * ROWS + r] = lds[it];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // twiddle matrices. TW[tbl][idx][k] = row k of "multiply by point(2 * (idx << 10 tbl))";
 // TWC[tbl][idx] = that point. Rows/points of a block index j are the XOR over tbl of entry (j >> 10 tbl) & 1023.
 #define TW_TABLES 3
@@ -224,9 +346,9 @@ __device__ __forceinline__ void mul_blocks(const twid &tw, const uint32_t y0[32]
             const uint32_t r = tw.row[k];
 #pragma unroll
             for (int j = 0; j < B; j++) {
-                const uint32_t m = 0u - ((r >> j) & 1u);
-                a0 ^= y0[blk * B + j] & m;
-                a1 ^= y1[blk * B + j] & m;
+                const uint32_t m = 0u - ((r >> j) & 1u);  // wave-uniform: s_bfe_i32
+                a0 = XAND(a0, y0[blk * B + j], m);
+                a1 = XAND(a1, y1[blk * B + j], m);
             }
             t0[blk * B + k] = a0;
             t1[blk * B + k] = a1;
@@ -379,8 +501,8 @@ __device__ __forceinline__ void low_level(uint32_t W0[32], uint32_t W1[32], uint
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t m = d_MPOS[(I * 8 + k) * 8 + j];
-                    a0 ^= v0[blk * 8 + j] & m;
-                    a1 ^= v1[blk * 8 + j] & m;
+                    a0 = XAND(a0, v0[blk * 8 + j], m);
+                    a1 = XAND(a1, v1[blk * 8 + j], m);
                 }
                 t0[blk * 8 + k] ^= a0;
                 t1[blk * 8 + k] ^= a1;
@@ -431,8 +553,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int j = 0; j < 32; j++) {
                 const uint32_t m = M[k * 32 + j];
-                a0 ^= W0[j] & m;
-                a1 ^= W1[j] & m;
+                a0 = XAND(a0, W0[j], m);
+                a1 = XAND(a1, W1[j], m);
             }
             t0[k] = a0;
             t1[k] = a1;
@@ -494,23 +616,40 @@ __global__ void __launch_bounds__(256) k_qc_unpack(uint32_t *__restrict__ D, uin
 }
 
 // K9: overlap-add of the 31-bit product elements and transpose back to Blocks:
-// T[16*(32w+p) + t] bit row = C_t[w] ^ (C_{16+t}[w] << 1 | C_{16+t}[w-1] >> 31), bit p
-__global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ D, uint64_t nw, blk_t *__restrict__ T) {
-    __shared__ uint32_t tile[4][512 * 4];
+// T[16*(32w+p) + t] bit row = C_t[w] ^ (C_{16+t}[w] << 1 | C_{16+t}[w-1] >> 31), bit p.
+// One block = 2 consecutive words w; the slabs are staged through LDS (33-word padded groups of 32 rows)
+// so that both the global reads and the Block stores are coalesced.
+#define ST_W 2
+__global__ void __launch_bounds__(128) k_qc_store(const uint32_t *__restrict__ D, uint64_t nw, blk_t *__restrict__ T) {
+    __shared__ uint32_t slab[(ST_W * 128 + 64) * 33];  // [hi planes of w0-1 | w0 | w0+1], group = plane*4 + row/32
+    __shared__ uint32_t tile[ST_W][512 * 4];
+    const uint64_t w0 = (uint64_t)blockIdx.x * ST_W;
+    // stage: groups 0..63 = planes 16..31 of w0-1; groups 64.. = all planes of w0, w0+1
+    for (uint32_t i = threadIdx.x; i < (ST_W * 4096 + 2048) / 4; i += blockDim.x) {
+        uint32_t x = 4 * i;  // word index in the staged range
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (x < 2048) {
+            if (w0 > 0) v = *(const uint4 *)(D + ((w0 - 1) * 32 + 16) * ROWS + x);
+        } else {
+            uint64_t w = w0 + (x - 2048) / 4096;
+            if (w < nw) v = *(const uint4 *)(D + w0 * 32 * ROWS + (x - 2048));
+        }
+        uint32_t g = x >> 5, b = x & 31;
+        uint32_t *d = slab + g * 33 + b;
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t w = w0 + wave;
     if (w < nw) {
         const uint32_t t = lane >> 2, q = lane & 3;
         uint32_t a[32];
-        const uint32_t *lo = D + (w * 32 + t) * ROWS + 32 * q;
-        const uint32_t *hi = D + (w * 32 + 16 + t) * ROWS + 32 * q;
-        const uint32_t *hp = w ? D + ((w - 1) * 32 + 16 + t) * ROWS + 32 * q : nullptr;
+        const uint32_t *lo = slab + (64 + wave * 128 + t * 4 + q) * 33;
+        const uint32_t *hi = slab + (64 + wave * 128 + (16 + t) * 4 + q) * 33;
+        // previous word's hi planes: for wave 0 the staged w0-1 copy, else the preceding slab
+        const uint32_t *hp = wave == 0 ? slab + (t * 4 + q) * 33 : slab + (64 + (wave - 1) * 128 + (16 + t) * 4 + q) * 33;
 #pragma unroll
-        for (int b = 0; b < 32; b++) {
-            uint32_t v = lo[b] ^ (hi[b] << 1);
-            if (hp) v ^= hp[b] >> 31;
-            a[b] = v;
-        }
+        for (int b = 0; b < 32; b++) a[b] = lo[b] ^ (hi[b] << 1) ^ (hp[b] >> 31);
         transpose32(a);
 #pragma unroll
         for (int p = 0; p < 32; p++) tile[wave][(16 * p + t) * 4 + q] = a[p];
@@ -604,23 +743,48 @@ static inline unsigned gridn(uint64_t n, unsigned block, unsigned cap = 65535u *
     return (unsigned)(g > cap ? cap : g);
 }
 
-// runs the conversion on `bufs[cur]`, ping-ponging; returns index of the buffer holding the result
+static inline uint32_t ilog2(uint64_t x) {
+    uint32_t l = 0;
+    while ((1ull << l) < x) l++;
+    return l;
+}
+
+// runs the conversion on `bufs[cur]`; phases with chunk > 2^16 elements go through the generic ping-pong
+// kernel, the rest through the fused LDS tile kernel (in place). Returns the buffer index holding the result.
 template <int NP>
 static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, uint64_t nwords, bool inverse) {
     std::vector<phase_t> ph;
     conv_rec(ph, ell_elems, 1);
+    const uint32_t tb = ell_elems < 16 ? ell_elems : 16;
+    std::vector<phase_t> big;
+    conv_phases small;
+    small.n = 0;
+    for (auto &p : ph) {
+        if (p.chunk > (1ull << tb)) {
+            big.push_back(p);  // conv_rec emits every chunk > 2^16 phase before the tile-local ones
+        } else {
+            small.lchunk[small.n] = (uint8_t)ilog2(p.chunk);
+            small.lpw[small.n] = (uint8_t)ilog2(p.pw);
+            small.n++;
+        }
+    }
     const uint64_t total = nwords * NP * ROWS;
     const unsigned grid = gridn(total, 256, 1u << 20);
+    const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * NP * 8);
+    const int kid = NP == 16 ? KID_CONV16 : KID_CONV32;
+    const int kid_t = NP == 16 ? KID_CONV16_TILE : KID_CONV32_TILE;
     if (!inverse) {
-        for (size_t i = 0; i < ph.size(); i++) {
-            SOT_LAUNCH(c, NP == 16 ? KID_CONV16 : KID_CONV32, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
-                               ph[i].chunk, ph[i].pw, ph[i].half, 0);
+        for (size_t i = 0; i < big.size(); i++) {
+            SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords, big[i].chunk,
+                       big[i].pw, big[i].half, 0);
             cur ^= 1;
         }
+        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
-        for (size_t i = ph.size(); i-- > 0;) {
-            SOT_LAUNCH(c, NP == 16 ? KID_CONV16 : KID_CONV32, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
-                               ph[i].chunk, ph[i].pw, ph[i].half, 1);
+        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
+        for (size_t i = big.size(); i-- > 0;) {
+            SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords, big[i].chunk,
+                       big[i].pw, big[i].half, 1);
             cur ^= 1;
         }
     }
@@ -752,7 +916,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     SOT_LAUNCH(c, KID_QC_UNPACK, k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), c->D0, g.nw);
     uint32_t *db[2] = {c->D0, c->D1};
     int cur = run_conversion<32>(c, db, 0, g.ell, g.nw, true);
-    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, 4)), dim3(256), db[cur], g.nw, c->T);
+    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, ST_W)), dim3(64 * ST_W), db[cur], g.nw, c->T);
     SOT_LAUNCH(c, KID_QC_FINAL, k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), V, nb128, cf.P, g.S, g.tail,
                        cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
     SOT_HIP(hipGetLastError());

@@ -68,6 +68,8 @@ enum sot_kid {
     KID_CONV32,
     KID_QC_STORE,
     KID_QC_FINAL,
+    KID_CONV16_TILE,
+    KID_CONV32_TILE,
     KID_COUNT
 };
 extern const char *const SOT_KID_NAMES[KID_COUNT];
