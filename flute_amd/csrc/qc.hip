@@ -300,6 +300,116 @@ __global__ void __launch_bounds__(CT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2c: all conversion phases whose chunk spans several 2^16-element units, fused in LDS, in place.
+// Tile = every unit u (NU = 2^(ell-16)) x NC columns x 32 rows of one plane; column 0 is a halo: the word that
+// linearly precedes column 1 (offset o0 - 1, or offset 2047 of the same unit when o0 == 0, "wrap"). Two kinds of
+// phases occur here (gf2fft_model.conversion_phases): pw >= 2^16 (whole units move: plain word XORs between
+// units) and pw < 32 (a sub-word shift along the linear element index). The five sub-word phases shift by at
+// most 31 bits in total, so one halo word per unit supplies every bit that crosses into the tile; its low bits
+// decay phase by phase and it is never written back.
+#define TOPK_ROWS 32
+__device__ __forceinline__ void top_fold(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
+                                         uint32_t lpw) {
+    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1, nchunks = NU / chunk_u;
+    if (lpw >= 16) {
+        const uint32_t pw_u = 1u << (lpw - 16);
+        const uint32_t items = nchunks * pw_u * NC * TOPK_ROWS;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t cr = it % (NC * TOPK_ROWS), uj = it / (NC * TOPK_ROWS);
+            uint32_t c = uj / pw_u, j = uj % pw_u;
+            uint32_t ud = c * chunk_u + half_u + j, us = ud + half_u - pw_u;
+            lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
+        }
+    } else if (wrap) {
+        const uint32_t pw = 1u << lpw;
+        const uint32_t items = nchunks * TOPK_ROWS;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it % TOPK_ROWS, c = it / TOPK_ROWS;
+            uint32_t ud = c * chunk_u + half_u, us = c * chunk_u + chunk_u - 1;
+            lds[(ud * NC + 1) * TOPK_ROWS + r] ^= lds[(us * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+        }
+    }
+}
+
+__device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
+                                          uint32_t lpw) {
+    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1;
+    const uint32_t items = (NU / 2) * NC * TOPK_ROWS;
+    if (lpw >= 16) {
+        const uint32_t pw_u = 1u << (lpw - 16);
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t cr = it % (NC * TOPK_ROWS), ui = it / (NC * TOPK_ROWS);
+            uint32_t c = ui / half_u, d = ui % half_u;
+            if (d >= pw_u) {
+                uint32_t ud = c * chunk_u + d, us = c * chunk_u + half_u + d - pw_u;
+                lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
+            }
+        }
+    } else {
+        const uint32_t pw = 1u << lpw;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, ui = it / (NC * TOPK_ROWS);
+            uint32_t c = ui / half_u, d = ui % half_u;
+            uint32_t ud = c * chunk_u + d, us = ud + half_u;
+            uint32_t h = lds[(us * NC + col) * TOPK_ROWS + r] << pw;
+            if (col >= 2) {
+                h |= lds[(us * NC + col - 1) * TOPK_ROWS + r] >> (32 - pw);
+            } else if (col == 1) {
+                if (!wrap)
+                    h |= lds[(us * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+                else if (d != 0)  // offset 0: the preceding word is offset 2047 of the previous unit
+                    h |= lds[((us - 1) * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+            }
+            lds[(ud * NC + col) * TOPK_ROWS + r] ^= h;
+        }
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(CT_THREADS)
+    k_conv_top(uint32_t *__restrict__ D, uint32_t lnu, uint32_t NC, conv_phases ph, int inverse) {
+    __shared__ uint32_t lds[32768 + 1024];
+    const uint32_t NU = 1u << lnu;
+    const uint32_t W = NC - 1;  // payload columns
+    // blockIdx.x = ((colblock * NP) + plane) * 4 + rowgrp
+    const uint32_t rowgrp = blockIdx.x & 3;
+    const uint32_t plane = (blockIdx.x >> 2) % NP;
+    const uint32_t cb = (blockIdx.x >> 2) / NP;
+    const uint32_t o0 = cb * W;
+    const bool wrap = o0 == 0;
+    uint32_t *g = D + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
+    const uint32_t items = NU * NC * TOPK_ROWS;
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
+        uint32_t o = col ? o0 + col - 1 : (wrap ? 2047u : o0 - 1);
+        uint32_t v = 0;
+        if (o < 2048) v = g[((uint64_t)u * 2048 + o) * NP * ROWS + r];
+        lds[it] = v;
+    }
+    __syncthreads();
+    for (int q = 0; q < ph.n; q++) {
+        const int i = inverse ? ph.n - 1 - q : q;
+        const uint32_t lchunk = ph.lchunk[i], lpw = ph.lpw[i];
+        if (!inverse) {
+            top_fold(lds, NU, NC, wrap, lchunk, lpw);
+            __syncthreads();
+            top_shift(lds, NU, NC, wrap, lchunk, lpw);
+        } else {
+            top_shift(lds, NU, NC, wrap, lchunk, lpw);
+            __syncthreads();
+            top_fold(lds, NU, NC, wrap, lchunk, lpw);
+        }
+        __syncthreads();
+    }
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
+        if (col == 0) continue;
+        uint32_t o = o0 + col - 1;
+        if (o < 2048) g[((uint64_t)u * 2048 + o) * NP * ROWS + r] = lds[it];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // twiddle matrices. TW[tbl][idx][k] = row k of "multiply by point(2 * (idx << 10 tbl))";
 // TWC[tbl][idx] = that point. Rows/points of a block index j are the XOR over tbl of entry (j >> 10 tbl) & 1023.
 #define TW_TABLES 3
@@ -338,20 +448,29 @@ __device__ __forceinline__ void load_twid(const uint32_t *__restrict__ TW, const
 template <int B>
 __device__ __forceinline__ void mul_blocks(const twid &tw, const uint32_t y0[32], const uint32_t y1[32], uint32_t t0[32],
                                            uint32_t t1[32]) {
+    // KB outputs at a time, input index outermost: 2*KB independent accumulation chains in flight
+    constexpr int KB = 4;
 #pragma unroll
     for (int blk = 0; blk < 32 / B; blk++) {
 #pragma unroll
-        for (int k = 0; k < B; k++) {
-            uint32_t a0 = 0, a1 = 0;
-            const uint32_t r = tw.row[k];
+        for (int k0 = 0; k0 < B; k0 += KB) {
+            uint32_t a0[KB], a1[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) a0[kk] = a1[kk] = 0;
 #pragma unroll
             for (int j = 0; j < B; j++) {
-                const uint32_t m = 0u - ((r >> j) & 1u);  // wave-uniform: s_bfe_i32
-                a0 = XAND(a0, y0[blk * B + j], m);
-                a1 = XAND(a1, y1[blk * B + j], m);
+#pragma unroll
+                for (int kk = 0; kk < KB; kk++) {
+                    const uint32_t m = 0u - ((tw.row[k0 + kk] >> j) & 1u);  // wave-uniform: s_bfe_i32
+                    a0[kk] = XAND(a0[kk], y0[blk * B + j], m);
+                    a1[kk] = XAND(a1[kk], y1[blk * B + j], m);
+                }
             }
-            t0[blk * B + k] = a0;
-            t1[blk * B + k] = a1;
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) {
+                t0[blk * B + k0 + kk] = a0[kk];
+                t1[blk * B + k0 + kk] = a1[kk];
+            }
         }
     }
 }
@@ -456,6 +575,101 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4b: up to four consecutive word-pair levels fused through LDS. Tile = 2^nlev words at word stride 2^d0
+// (levels i = 5 + d0 .. 5 + d0 + nlev - 1) x 32 planes x 64 rows = 128 KiB at nlev = 4. One wave per
+// butterfly pair and level (the twiddle is wave uniform), lane = row.
+template <int B>
+__device__ __forceinline__ void mul_blocks1(const twid &tw, const uint32_t y[32], uint32_t t[32]) {
+    constexpr int KB = 8;
+#pragma unroll
+    for (int blk = 0; blk < 32 / B; blk++) {
+#pragma unroll
+        for (int k0 = 0; k0 < B; k0 += KB) {
+            uint32_t a[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) a[kk] = 0;
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+#pragma unroll
+                for (int kk = 0; kk < KB; kk++)
+                    a[kk] = XAND(a[kk], y[blk * B + j], 0u - ((tw.row[k0 + kk] >> j) & 1u));
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) t[blk * B + k0 + kk] = a[kk];
+        }
+    }
+}
+
+#define FT_ROWS 64
+#define FT_THREADS 512
+template <bool INV>
+__global__ void __launch_bounds__(FT_THREADS)
+    k_fft_tile(uint32_t *__restrict__ D, uint32_t d0, uint32_t nlev, const uint32_t *__restrict__ TW,
+               const uint32_t *__restrict__ TWC) {
+    __shared__ uint32_t lds[16 * 32 * FT_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwt = 1u << nlev;
+    const uint32_t rh = blockIdx.x & 1;
+    const uint64_t ti = blockIdx.x >> 1;
+    const uint64_t wbase = ((ti >> d0) << (d0 + nlev)) | (ti & (((uint64_t)1 << d0) - 1));
+    uint32_t *g = D + rh * FT_ROWS + lane;
+    // load: (wl, k) segments of 64 rows
+    for (uint32_t s = wave; s < nwt * 32; s += FT_THREADS / 64) {
+        uint32_t wl = s >> 5, k = s & 31;
+        lds[s * FT_ROWS + lane] = g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS];
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < nlev; q++) {
+        const uint32_t lv = INV ? q : nlev - 1 - q;
+        for (uint32_t pr = wave; pr < nwt / 2; pr += FT_THREADS / 64) {
+            const uint32_t a = ((pr >> lv) << (lv + 1)) | (pr & ((1u << lv) - 1));
+            const uint32_t b = a + (1u << lv);
+            const uint64_t w0 = wbase + ((uint64_t)a << d0);
+            const uint32_t j = (uint32_t)(w0 >> (d0 + lv + 1));
+            twid tw;
+            load_twid(TW, TWC, j, tw);
+            uint32_t *px = lds + (a * 32) * FT_ROWS + lane;
+            uint32_t *py = lds + (b * 32) * FT_ROWS + lane;
+            uint32_t x[32], y[32], t[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                x[k] = px[k * FT_ROWS];
+                y[k] = py[k * FT_ROWS];
+            }
+            if (INV) {
+#pragma unroll
+                for (int k = 0; k < 32; k++) y[k] ^= x[k];
+            }
+            if (tw.c != 0) {
+                if (tw.c < (1u << 8))
+                    mul_blocks1<8>(tw, y, t);
+                else if (tw.c < (1u << 16))
+                    mul_blocks1<16>(tw, y, t);
+                else
+                    mul_blocks1<32>(tw, y, t);
+#pragma unroll
+                for (int k = 0; k < 32; k++) x[k] ^= t[k];
+            }
+            if (!INV) {
+#pragma unroll
+                for (int k = 0; k < 32; k++) y[k] ^= x[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                px[k * FT_ROWS] = x[k];
+                py[k * FT_ROWS] = y[k];
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t s = wave; s < nwt * 32; s += FT_THREADS / 64) {
+        uint32_t wl = s >> 5, k = s & 31;
+        g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS] = lds[s * FT_ROWS + lane];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5: the five intra-word levels (4..0 forward, 0..4 inverse), optionally with the pointwise multiply by
 // FFT(a) in between. Level i pairs bit positions p and p + 2^i; the twiddle of position p is
 // point(2*((32w+p) >> (i+1))) = point(w << (5-i)) ^ point(2*(p >> (i+1))): a wave-uniform part and a
@@ -548,16 +762,22 @@ __global__ void __launch_bounds__(256)
         const uint32_t *M = Amat + w * 1024;  // wave-uniform address
         uint32_t t0[32], t1[32];
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-            uint32_t a0 = 0, a1 = 0;
+        for (int k0 = 0; k0 < 32; k0 += 4) {
+            uint32_t a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 32; j++) {
-                const uint32_t m = M[k * 32 + j];
-                a0 = XAND(a0, W0[j], m);
-                a1 = XAND(a1, W1[j], m);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const uint32_t m = M[(k0 + kk) * 32 + j];
+                    a0[kk] = XAND(a0[kk], W0[j], m);
+                    a1[kk] = XAND(a1[kk], W1[j], m);
+                }
             }
-            t0[k] = a0;
-            t1[k] = a1;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                t0[k0 + kk] = a0[kk];
+                t1[k0 + kk] = a1[kk];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 32; k++) {
@@ -773,19 +993,44 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * NP * 8);
     const int kid = NP == 16 ? KID_CONV16 : KID_CONV32;
     const int kid_t = NP == 16 ? KID_CONV16_TILE : KID_CONV32_TILE;
+    // the multi-unit phases fuse into k_conv_top when each is a whole-unit move or a sub-word shift
+    conv_phases top;
+    top.n = 0;
+    bool top_ok = !big.empty() && ell_elems > 16 && ell_elems - 16 <= 7;
+    uint32_t shift_sum = 0;
+    for (auto &p : big) {
+        uint32_t lpw = ilog2(p.pw);
+        if (lpw >= 5 && lpw < 16) top_ok = false;
+        if (lpw < 5) shift_sum += 1u << lpw;
+        top.lchunk[top.n] = (uint8_t)ilog2(p.chunk);
+        top.lpw[top.n] = (uint8_t)lpw;
+        top.n++;
+    }
+    if (shift_sum > 31) top_ok = false;
+    const uint32_t lnu = top_ok ? ell_elems - 16 : 0;
+    const uint32_t NC = top_ok ? 1024u >> lnu : 0;  // NU * NC * 32 rows = 32768 words
+    const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * NP * 4) : 0;
     if (!inverse) {
-        for (size_t i = 0; i < big.size(); i++) {
-            SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords, big[i].chunk,
-                       big[i].pw, big[i].half, 0);
-            cur ^= 1;
+        if (top_ok) {
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], lnu, NC, top, 0);
+        } else {
+            for (size_t i = 0; i < big.size(); i++) {
+                SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
+                           big[i].chunk, big[i].pw, big[i].half, 0);
+                cur ^= 1;
+            }
         }
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
-        for (size_t i = big.size(); i-- > 0;) {
-            SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords, big[i].chunk,
-                       big[i].pw, big[i].half, 1);
-            cur ^= 1;
+        if (top_ok) {
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], lnu, NC, top, 1);
+        } else {
+            for (size_t i = big.size(); i-- > 0;) {
+                SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
+                           big[i].chunk, big[i].pw, big[i].half, 1);
+                cur ^= 1;
+            }
         }
     }
     return cur;
@@ -798,10 +1043,14 @@ static int forward_to_D(sot_ctx *c, int xcur) {
     xcur = run_conversion<16>(c, xb, xcur, g.ell - 1, g.nw_in, false);
     SOT_LAUNCH(c, KID_QC_EXPAND, k_qc_expand, dim3(gridn(g.nw_in * ROWS, 256, 1u << 20)), dim3(256), xb[xcur],
                        c->D0, g.nw_in);
-    const uint64_t npairs = g.nw / 2;
-    for (int i = (int)g.ell - 2; i >= 5; i--)
-        SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_level<false>, dim3(gridn(npairs, 4)), dim3(256), c->D0, npairs,
-                           (uint32_t)(i - 5), c->TW, c->TWC);
+    // word-pair levels i = ell-2 .. 5 (d = i - 5), four per pass from the top
+    for (int dtop = (int)g.ell - 7; dtop >= 0;) {
+        int nlev = dtop + 1 < 4 ? dtop + 1 : 4;
+        int d0 = dtop - nlev + 1;
+        SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS), c->D0,
+                   (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        dtop = d0 - 1;
+    }
     SOT_HIP(hipGetLastError());
     return SOT_OK;
 }
@@ -909,10 +1158,13 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     SOT_TRY(forward_to_D(c, 0));
     SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(gridn(g.nw, 4)), dim3(256), c->D0, g.nw, c->TW, c->TWC,
                        c->Amat);
-    const uint64_t npairs = g.nw / 2;
-    for (int i = 5; i < (int)g.ell; i++)
-        SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_level<true>, dim3(gridn(npairs, 4)), dim3(256), c->D0, npairs,
-                           (uint32_t)(i - 5), c->TW, c->TWC);
+    for (int d0 = 0; d0 <= (int)g.ell - 6;) {
+        int rem = (int)g.ell - 5 - d0;
+        int nlev = rem < 4 ? rem : 4;
+        SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS), c->D0,
+                   (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        d0 += nlev;
+    }
     SOT_LAUNCH(c, KID_QC_UNPACK, k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), c->D0, g.nw);
     uint32_t *db[2] = {c->D0, c->D1};
     int cur = run_conversion<32>(c, db, 0, g.ell, g.nw, true);
