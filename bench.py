@@ -74,24 +74,20 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from flute_amd import dist as fd
+    rank, local_rank, world = fd.env_world()
     if world != args.gpus and world > 1:
         args.gpus = world
 
     import torch
-    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = fd.init("nccl", rank, world, device_id=torch.device("cuda", local_rank))
 
     import flute_amd as fa
     n = 1 << args.log2n
     eng = fa.Engine(n, device=local_rank)
     conf = eng.conf
-    rng = np.random.default_rng(1000 + rank)
+    rng = np.random.default_rng(fd.instance_seed(rank))
     x = fa.fake_base(conf, rng)  # direction X: this party sends
     y = fa.fake_base(conf, rng)  # direction Y: this party receives
     delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
@@ -113,8 +109,7 @@ def main():
     def barrier():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        fd.barrier(world)
 
     for _ in range(args.warmup):
         step()
@@ -131,10 +126,7 @@ def main():
     if not args.no_prof:
         eng.prof_enable(False)
         prof = eng.prof_read()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = fd.max_over_ranks(dt, world, device="cuda")
 
     # size-independent correctness property on the last step (check_correlated, silent_ot/mod.rs:744-777
     # cannot be used here because X and Y are different OT instances; the MT relation needs the peer).
@@ -142,7 +134,7 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * 2.0 * n * args.steps / dt
+        value = fd.aggregate_ots_per_s(n, args.steps, dt, world)
         out = {
             "metric": "random OTs/sec for 2^%d silent-OT expansion (sender+receiver per party, MT bits)" % args.log2n,
             "value": value, "unit": "OTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,92 @@
+"""Full-size GPU checks: n = 2^20 bit-exact against the oracle; n = 2^24 (BASELINE.json's size) through the
+size-independent properties of the reference's own tests (check_correlated / check_random, silent_ot/mod.rs:744-795;
+MT relation, gmw/src/mul_triple/silent_ot.rs:166-168)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LSB_CLR = np.uint64(0xFFFFFFFFFFFFFFFE)
+
+
+def test_2pow20_pipeline_matches_oracle(orc):
+    import flute_amd as fa
+    n, T = 1 << 20, 4
+    conf = orc.configure(n)
+    rng = np.random.default_rng(2020)
+    msg2, msg, choices = orc.fake_base(conf, rng)
+    delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    orc.use_reference_multiplier(True)  # the reference's bitpolymul2 when oracle/_ref exists (else Karatsuba)
+    try:
+        o_s, o_B, o_rT, o_sums, o_last = orc.random_silent_send(conf, msg2, delta, seed, T)
+        o_r, o_ch, o_A, _ = orc.random_silent_receive(conf, msg, choices, o_sums, o_last)
+    finally:
+        orc.use_reference_multiplier(False)
+    oa, ob, oc = orc.mt_bits(o_s.reshape(-1, 2), o_r, o_ch)
+    eng = fa.Engine(n)
+    try:
+        sums, last = eng.sender_expand(msg2, delta, seed, T)
+        assert np.array_equal(sums, o_sums) and np.array_equal(last, o_last)
+        assert np.array_equal(eng.download_rT(0), o_rT)
+        eng.qc_encode(0)
+        assert np.array_equal(eng.download_encoded(0), o_B)
+        assert np.array_equal(eng.sender_hash(delta), o_s)
+        eng.receiver_expand(msg, choices, sums, last)
+        eng.qc_encode(1, eng.points(choices))
+        assert np.array_equal(eng.download_encoded(1), o_A)
+        r, ch = eng.receiver_hash()
+        assert np.array_equal(r, o_r) and np.array_equal(ch, o_ch)
+        a, b, c = eng.mt_bits(delta)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob) and np.array_equal(c, oc)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("log2n", [24])
+def test_full_size_properties(log2n):
+    import flute_amd as fa
+    n, T = 1 << log2n, 4
+    e0, e1 = fa.Engine(n), fa.Engine(n)
+    try:
+        rng = np.random.default_rng(24)
+        x = fa.fake_base(e0.conf, rng)
+        y = fa.fake_base(e0.conf, rng)
+        d0, d1, s0, s1 = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+        # direction X: party 0 sends (e0 role 0), party 1 receives (e1 role 1); direction Y the other way round
+        tg0 = e0.sender_expand(x[0], d0, s0, T)
+        e0.qc_encode(0)
+        e1.receiver_expand(x[1], x[2], *tg0)
+        e1.qc_encode(1, e1.points(x[2]))
+        B = e0.download_encoded(0)
+        A = e1.download_encoded(1)
+        # check_correlated with packed choice bits
+        c = (A[:, 0] & np.uint64(1)).astype(bool)
+        assert 0.49 < c.mean() < 0.51
+        z = A ^ B
+        z[:, 0] &= LSB_CLR
+        dm = d0.copy()
+        dm[0] &= LSB_CLR
+        ok = np.where(c, (z[:, 0] == dm[0]) & (z[:, 1] == dm[1]), (z[:, 0] == 0) & (z[:, 1] == 0))
+        assert ok.all()
+        del z, ok
+        # check_random on a window of the hashed outputs
+        sm = e0.sender_hash(d0)
+        rm, ch = e1.receiver_hash()
+        sel = np.unpackbits(ch.view(np.uint8), bitorder="little")[:n].astype(np.int64)
+        assert np.array_equal(sel.astype(bool), c)
+        idx = np.arange(n)
+        assert np.array_equal(sm[idx, sel], rm)
+        assert not (sm[idx, 1 - sel] == rm).all(axis=1).any()
+        del sm, rm
+        # MT relation over all n triples
+        tg1 = e1.sender_expand(y[0], d1, s1, T)
+        e1.qc_encode(0)
+        e0.receiver_expand(y[1], y[2], *tg1)
+        e0.qc_encode(1, e0.points(y[2]))
+        a0, b0, c0 = e0.mt_bits(d0)
+        a1, b1, c1 = e1.mt_bits(d1)
+        assert np.array_equal(c0 ^ c1, (a0 ^ a1) & (b0 ^ b1))
+        assert 0.49 < np.unpackbits((a0 ^ a1).view(np.uint8)).mean() < 0.51
+    finally:
+        e0.close()
+        e1.close()
