@@ -12,6 +12,7 @@
 //   conversion -> overlap-add back to Blocks T -> fold mod x^P - 1 together with V0 and the short
 //   schoolbook "tail" terms for the few bits of a and V1 above the power-of-two FFT capacity.
 // The math (and the generators of the constant tables) is in gf2fft_model.py / gen_tables.py.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -367,7 +368,8 @@ __device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t N
 
 template <int NP>
 __global__ void __launch_bounds__(CT_THREADS)
-    k_conv_top(uint32_t *__restrict__ D, uint32_t lnu, uint32_t NC, conv_phases ph, int inverse) {
+    k_conv_top(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, uint32_t lnu, uint32_t NC,
+               conv_phases ph, int inverse) {
     __shared__ uint32_t lds[32768 + 1024];
     const uint32_t NU = 1u << lnu;
     const uint32_t W = NC - 1;  // payload columns
@@ -377,7 +379,9 @@ __global__ void __launch_bounds__(CT_THREADS)
     const uint32_t cb = (blockIdx.x >> 2) / NP;
     const uint32_t o0 = cb * W;
     const bool wrap = o0 == 0;
-    uint32_t *g = D + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
+    // out of place: neighbouring tiles read each other's edge words as halos
+    const uint32_t *g = Din + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
+    uint32_t *go = Dout + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
     const uint32_t items = NU * NC * TOPK_ROWS;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
         uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
@@ -405,7 +409,7 @@ __global__ void __launch_bounds__(CT_THREADS)
         uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
         if (col == 0) continue;
         uint32_t o = o0 + col - 1;
-        if (o < 2048) g[((uint64_t)u * 2048 + o) * NP * ROWS + r] = lds[it];
+        if (o < 2048) go[((uint64_t)u * 2048 + o) * NP * ROWS + r] = lds[it];
     }
 }
 
@@ -996,7 +1000,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     // the multi-unit phases fuse into k_conv_top when each is a whole-unit move or a sub-word shift
     conv_phases top;
     top.n = 0;
-    bool top_ok = !big.empty() && ell_elems > 16 && ell_elems - 16 <= 7;
+    bool top_ok = !big.empty() && ell_elems > 16 && ell_elems - 16 <= 7 && !getenv("SOT_NO_TOP");
     uint32_t shift_sum = 0;
     for (auto &p : big) {
         uint32_t lpw = ilog2(p.pw);
@@ -1012,7 +1016,8 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * NP * 4) : 0;
     if (!inverse) {
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], lnu, NC, top, 0);
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, NC, top, 0);
+            cur ^= 1;
         } else {
             for (size_t i = 0; i < big.size(); i++) {
                 SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
@@ -1024,7 +1029,8 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     } else {
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], lnu, NC, top, 1);
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, NC, top, 1);
+            cur ^= 1;
         } else {
             for (size_t i = big.size(); i-- > 0;) {
                 SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,

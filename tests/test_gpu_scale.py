@@ -90,3 +90,48 @@ def test_full_size_properties(log2n):
     finally:
         e0.close()
         e1.close()
+
+
+@pytest.mark.parametrize("log2n", [21, 22, 23])
+def test_fused_conversion_equals_generic_path(log2n, monkeypatch):
+    """The fused multi-unit conversion kernel (k_conv_top) against the one-phase-per-launch generic kernels,
+    bit for bit, at sizes where several multi-unit phases exist (check_correlated cannot see an error that
+    sender and receiver share)."""
+    import flute_amd as fa
+    n = 1 << log2n
+    eng = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(log2n)
+        msg2, msg, choices = fa.fake_base(eng.conf, rng)
+        delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        eng.sender_expand(msg2, delta, seed, 4)
+        eng.qc_encode(0)
+        fused = eng.download_encoded(0)
+        monkeypatch.setenv("SOT_NO_TOP", "1")
+        eng.qc_encode(0)
+        generic = eng.download_encoded(0)
+        assert np.array_equal(fused, generic)
+    finally:
+        eng.close()
+
+
+def test_2pow22_encode_matches_oracle_with_reference_multiplier(orc):
+    """n = 2^22: QC encode of a random rT against the oracle whose products come from the reference's own
+    bitpolymul_2_128 (oracle/_ref)."""
+    import flute_amd as fa
+    if not orc.use_reference_multiplier(True):
+        pytest.skip("oracle/_ref absent")
+    try:
+        n = 1 << 22
+        conf = orc.configure(n)
+        rng = np.random.default_rng(22)
+        rT = rng.integers(0, 2 ** 64, size=(128, int(conf.cols), 2), dtype=np.uint64)
+        want = orc.qc_dual_encode(conf, rT)
+    finally:
+        orc.use_reference_multiplier(False)
+    eng = fa.Engine(n)
+    try:
+        assert np.array_equal(eng.qc_dual_encode_host(0, rT), want)
+    finally:
+        eng.close()
