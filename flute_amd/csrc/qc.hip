@@ -311,13 +311,14 @@ __global__ void __launch_bounds__(CT_THREADS)
 #define TOPK_ROWS 32
 __device__ __forceinline__ void top_fold(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
                                          uint32_t lpw) {
-    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1, nchunks = NU / chunk_u;
+    const uint32_t lcr = 31 - __clz(NC * TOPK_ROWS);  // NC and TOPK_ROWS are powers of two
+    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1, nchunks = NU >> (lchunk - 16);
     if (lpw >= 16) {
         const uint32_t pw_u = 1u << (lpw - 16);
         const uint32_t items = nchunks * pw_u * NC * TOPK_ROWS;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t cr = it % (NC * TOPK_ROWS), uj = it / (NC * TOPK_ROWS);
-            uint32_t c = uj / pw_u, j = uj % pw_u;
+            uint32_t cr = it & ((1u << lcr) - 1), uj = it >> lcr;
+            uint32_t c = uj >> (lpw - 16), j = uj & (pw_u - 1);
             uint32_t ud = c * chunk_u + half_u + j, us = ud + half_u - pw_u;
             lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
         }
@@ -334,13 +335,15 @@ __device__ __forceinline__ void top_fold(uint32_t *lds, uint32_t NU, uint32_t NC
 
 __device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
                                           uint32_t lpw) {
+    const uint32_t lcr = 31 - __clz(NC * TOPK_ROWS);
+    const uint32_t lhalf = lchunk - 17;
     const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1;
     const uint32_t items = (NU / 2) * NC * TOPK_ROWS;
     if (lpw >= 16) {
         const uint32_t pw_u = 1u << (lpw - 16);
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t cr = it % (NC * TOPK_ROWS), ui = it / (NC * TOPK_ROWS);
-            uint32_t c = ui / half_u, d = ui % half_u;
+            uint32_t cr = it & ((1u << lcr) - 1), ui = it >> lcr;
+            uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
             if (d >= pw_u) {
                 uint32_t ud = c * chunk_u + d, us = c * chunk_u + half_u + d - pw_u;
                 lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
@@ -349,8 +352,8 @@ __device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t N
     } else {
         const uint32_t pw = 1u << lpw;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, ui = it / (NC * TOPK_ROWS);
-            uint32_t c = ui / half_u, d = ui % half_u;
+            uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), ui = it >> lcr;
+            uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
             uint32_t ud = c * chunk_u + d, us = ud + half_u;
             uint32_t h = lds[(us * NC + col) * TOPK_ROWS + r] << pw;
             if (col >= 2) {
@@ -368,10 +371,10 @@ __device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t N
 
 template <int NP>
 __global__ void __launch_bounds__(CT_THREADS)
-    k_conv_top(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, uint32_t lnu, uint32_t NC,
+    k_conv_top(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, uint32_t lnu, uint32_t lnc,
                conv_phases ph, int inverse) {
     __shared__ uint32_t lds[32768 + 1024];
-    const uint32_t NU = 1u << lnu;
+    const uint32_t NU = 1u << lnu, NC = 1u << lnc;
     const uint32_t W = NC - 1;  // payload columns
     // blockIdx.x = ((colblock * NP) + plane) * 4 + rowgrp
     const uint32_t rowgrp = blockIdx.x & 3;
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(CT_THREADS)
     uint32_t *go = Dout + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
     const uint32_t items = NU * NC * TOPK_ROWS;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
+        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), u = it >> (lnc + 5);
         uint32_t o = col ? o0 + col - 1 : (wrap ? 2047u : o0 - 1);
         uint32_t v = 0;
         if (o < 2048) v = g[((uint64_t)u * 2048 + o) * NP * ROWS + r];
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(CT_THREADS)
         __syncthreads();
     }
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) % NC, u = it / (NC * TOPK_ROWS);
+        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), u = it >> (lnc + 5);
         if (col == 0) continue;
         uint32_t o = o0 + col - 1;
         if (o < 2048) go[((uint64_t)u * 2048 + o) * NP * ROWS + r] = lds[it];
@@ -673,6 +676,99 @@ __global__ void __launch_bounds__(FT_THREADS)
     }
 }
 
+// K4c: same tile, 16 waves: every butterfly is split over two waves by plane half. Valid while every twiddle of
+// the pass lies in GF(2^16) (then multiply-by-twiddle acts on planes 0..15 and 16..31 independently with the
+// same 16x16 matrix): levels i >= ell - 16. Twice the waves per SIMD of k_fft_tile at the same LDS footprint.
+#define FT2_THREADS 1024
+template <bool INV>
+__global__ void __launch_bounds__(FT2_THREADS)
+    k_fft_tile2(uint32_t *__restrict__ D, uint32_t d0, uint32_t nlev, const uint32_t *__restrict__ TW,
+                const uint32_t *__restrict__ TWC) {
+    __shared__ uint32_t lds[16 * 32 * FT_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwt = 1u << nlev;
+    const uint32_t rh = blockIdx.x & 1;
+    const uint64_t ti = blockIdx.x >> 1;
+    const uint64_t wbase = ((ti >> d0) << (d0 + nlev)) | (ti & (((uint64_t)1 << d0) - 1));
+    uint32_t *g = D + rh * FT_ROWS + lane;
+    for (uint32_t s = wave; s < nwt * 32; s += FT2_THREADS / 64) {
+        uint32_t wl = s >> 5, k = s & 31;
+        lds[s * FT_ROWS + lane] = g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS];
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < nlev; q++) {
+        const uint32_t lv = INV ? q : nlev - 1 - q;
+        for (uint32_t itx = wave; itx < nwt; itx += FT2_THREADS / 64) {
+            const uint32_t pr = itx >> 1, hf = itx & 1;
+            const uint32_t a = ((pr >> lv) << (lv + 1)) | (pr & ((1u << lv) - 1));
+            const uint32_t b = a + (1u << lv);
+            const uint64_t w0 = wbase + ((uint64_t)a << d0);
+            const uint32_t j = (uint32_t)(w0 >> (d0 + lv + 1));
+            // 16x16 twiddle matrix rows (c < 2^16: rows 0..15, low 16 bits)
+            const uint32_t e0 = j & 1023, e1 = (j >> 10) & 1023, e2 = (j >> 20) & 1023;
+            const uint32_t c = TWC[e0] ^ TWC[1024 + e1] ^ TWC[2048 + e2];
+            uint32_t row[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                row[k] = TW[e0 * 32 + k] ^ TW[(1024 + e1) * 32 + k] ^ TW[(2048 + e2) * 32 + k];
+            uint32_t *px = lds + (a * 32 + hf * 16) * FT_ROWS + lane;
+            uint32_t *py = lds + (b * 32 + hf * 16) * FT_ROWS + lane;
+            uint32_t x[16], y[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                x[k] = px[k * FT_ROWS];
+                y[k] = py[k * FT_ROWS];
+            }
+            if (INV) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) y[k] ^= x[k];
+            }
+            if (c != 0) {
+                if (c < (1u << 8)) {
+#pragma unroll
+                    for (int blk = 0; blk < 2; blk++) {
+                        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+                            for (int kk = 0; kk < 8; kk++)
+                                acc[kk] = XAND(acc[kk], y[blk * 8 + jj], 0u - ((row[kk] >> jj) & 1u));
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) x[blk * 8 + kk] ^= acc[kk];
+                    }
+                } else {
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0 += 8) {
+                        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int jj = 0; jj < 16; jj++)
+#pragma unroll
+                            for (int kk = 0; kk < 8; kk++)
+                                acc[kk] = XAND(acc[kk], y[jj], 0u - ((row[k0 + kk] >> jj) & 1u));
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) x[k0 + kk] ^= acc[kk];
+                    }
+                }
+            }
+            if (!INV) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) y[k] ^= x[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                px[k * FT_ROWS] = x[k];
+                py[k * FT_ROWS] = y[k];
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t s = wave; s < nwt * 32; s += FT2_THREADS / 64) {
+        uint32_t wl = s >> 5, k = s & 31;
+        g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS] = lds[s * FT_ROWS + lane];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: the five intra-word levels (4..0 forward, 0..4 inverse), optionally with the pointwise multiply by
 // FFT(a) in between. Level i pairs bit positions p and p + 2^i; the twiddle of position p is
@@ -799,6 +895,115 @@ __global__ void __launch_bounds__(256)
         p[k * ROWS] = W0[k];
         p[k * ROWS + 64] = W1[k];
     }
+}
+
+// ---- single-row variant: one row per lane (half the registers: 4+ waves per SIMD keep both the VALU and the
+// scalar port that extracts the masks busy)
+template <int B, int I>
+__device__ __forceinline__ void low_mul_acc(const twid &tw, const uint32_t v[32], uint32_t W[32]) {
+    constexpr int KB = 8;
+#pragma unroll
+    for (int blk = 0; blk < 32 / B; blk++) {
+#pragma unroll
+        for (int k0 = 0; k0 < B; k0 += KB) {
+            uint32_t a[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) a[kk] = 0;
+#pragma unroll
+            for (int j = 0; j < B; j++) {
+#pragma unroll
+                for (int kk = 0; kk < KB; kk++)
+                    a[kk] = XAND(a[kk], v[blk * B + j], 0u - ((tw.row[k0 + kk] >> j) & 1u));
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++) W[blk * B + k0 + kk] ^= a[kk];
+        }
+    }
+}
+
+template <int I, bool INV>
+__device__ __forceinline__ void low_level1(uint32_t W[32], uint64_t w, const uint32_t *__restrict__ TW,
+                                           const uint32_t *__restrict__ TWC) {
+    const uint32_t A = lowmask(I);
+    constexpr int SH = 1 << I;
+    uint32_t v[32];
+    if (INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) v[k] = (W[k] >> SH) & A;  // y positions; the updates below touch x positions only
+    const uint32_t ju = (uint32_t)(w << (4 - I));
+    twid tw;
+    load_twid(TW, TWC, ju, tw);
+    if (tw.c != 0) {
+        if (tw.c < (1u << 8))
+            low_mul_acc<8, I>(tw, v, W);
+        else if (tw.c < (1u << 16))
+            low_mul_acc<16, I>(tw, v, W);
+        else
+            low_mul_acc<32, I>(tw, v, W);
+    }
+    if (I < 4) {
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t a = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) a = XAND(a, v[blk * 8 + j], d_MPOS[(I * 8 + k) * 8 + j]);
+                W[blk * 8 + k] ^= a;
+            }
+    }
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 4)
+    k_fft_low1(uint32_t *__restrict__ D, uint64_t nw, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC,
+               const uint32_t *__restrict__ Amat) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (w, row half)
+    if (item >= 2 * nw) return;
+    item = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(item >> 32)) << 32) |
+           __builtin_amdgcn_readfirstlane((uint32_t)item);
+    const uint64_t w = item >> 1;
+    uint32_t *p = D + w * 32 * ROWS + (item & 1) * 64 + lane;
+    uint32_t W[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) W[k] = p[k * ROWS];
+    low_level1<4, false>(W, w, TW, TWC);
+    low_level1<3, false>(W, w, TW, TWC);
+    low_level1<2, false>(W, w, TW, TWC);
+    low_level1<1, false>(W, w, TW, TWC);
+    low_level1<0, false>(W, w, TW, TWC);
+    if (MODE == 1) {
+        const uint32_t *M = Amat + w * 1024;  // wave-uniform address
+        uint32_t t[32];
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], W[j], M[(k0 + kk) * 32 + j]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) t[k0 + kk] = a[kk];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) W[k] = t[k];
+        low_level1<0, true>(W, w, TW, TWC);
+        low_level1<1, true>(W, w, TW, TWC);
+        low_level1<2, true>(W, w, TW, TWC);
+        low_level1<3, true>(W, w, TW, TWC);
+        low_level1<4, true>(W, w, TW, TWC);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) p[k * ROWS] = W[k];
 }
 
 // Amat[w][k][j] bit p = bit k of (FFT(a)[32 w + p] (x) 2^j); FFT(a) is row 0 of Da
@@ -1016,7 +1221,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * NP * 4) : 0;
     if (!inverse) {
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, NC, top, 0);
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 0);
             cur ^= 1;
         } else {
             for (size_t i = 0; i < big.size(); i++) {
@@ -1029,7 +1234,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     } else {
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, NC, top, 1);
+            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 1);
             cur ^= 1;
         } else {
             for (size_t i = big.size(); i-- > 0;) {
@@ -1053,8 +1258,12 @@ static int forward_to_D(sot_ctx *c, int xcur) {
     for (int dtop = (int)g.ell - 7; dtop >= 0;) {
         int nlev = dtop + 1 < 4 ? dtop + 1 : 4;
         int d0 = dtop - nlev + 1;
-        SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS), c->D0,
-                   (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        if (5 + d0 + 16 >= (int)g.ell)
+            SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile2<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT2_THREADS),
+                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        else
+            SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS),
+                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
         dtop = d0 - 1;
     }
     SOT_HIP(hipGetLastError());
@@ -1162,13 +1371,17 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw_in, 4)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
                        g.nw_in, c->X0);
     SOT_TRY(forward_to_D(c, 0));
-    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(gridn(g.nw, 4)), dim3(256), c->D0, g.nw, c->TW, c->TWC,
+    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low1<1>, dim3(gridn(2 * g.nw, 4)), dim3(256), c->D0, g.nw, c->TW, c->TWC,
                        c->Amat);
     for (int d0 = 0; d0 <= (int)g.ell - 6;) {
         int rem = (int)g.ell - 5 - d0;
         int nlev = rem < 4 ? rem : 4;
-        SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS), c->D0,
-                   (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        if (5 + d0 + 16 >= (int)g.ell)
+            SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile2<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT2_THREADS),
+                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
+        else
+            SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS),
+                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
         d0 += nlev;
     }
     SOT_LAUNCH(c, KID_QC_UNPACK, k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), c->D0, g.nw);
