@@ -17,7 +17,7 @@
 // roots: worker t = set % T owns AesRng(seed ^ t); its i-th group (i = set / T) takes keystream blocks
 // 8i..8i+7 (pprf.rs:115,128,135-137; util/aes_rng.rs:109-122)
 __global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t parts, blk_t *__restrict__ out) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
     if (tr >= parts) return;
@@ -29,7 +29,7 @@ __global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t p
 
 // generic-key CTR keystream: out[i] = AES_rk(LE128(first + i))   (util/aes_rng.rs:109-122)
 __global__ void k_aes_ctr(const uint32_t *__restrict__ rk, uint64_t first, blk_t *__restrict__ out, uint64_t n) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ uint32_t srk[44];
     aes_lds_fill(te);
     if (threadIdx.x < 44) srk[threadIdx.x] = rk[threadIdx.x];
@@ -43,7 +43,7 @@ __global__ void k_aes_ctr(const uint32_t *__restrict__ rk, uint64_t first, blk_t
 // mode 0: ECB encrypt, mode 1: x ^ AES_kh(x)
 __global__ void k_aes_ecb(const uint32_t *__restrict__ rk, const blk_t *__restrict__ in, blk_t *__restrict__ out,
                           uint64_t n, int mode) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ uint32_t srk[44];
     aes_lds_fill(te);
     if (threadIdx.x < 44) srk[threadIdx.x] = mode ? c_rk_fixed[AES_KH][threadIdx.x] : rk[threadIdx.x];
@@ -62,7 +62,7 @@ template <bool LAST>
 __global__ void __launch_bounds__(GGM_BLOCK)
     k_ggm_level(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t lvl, uint32_t nsets, uint64_t cols,
                 blk_t *__restrict__ sums /* this level: [set][2][8] */) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ blk_t red[GGM_BLOCK / 64][2][8];
     aes_lds_fill(te);
     const uint32_t set = blockIdx.y;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(GGM_BLOCK)
 __global__ void k_sender_treegrp(const blk_t *__restrict__ sums, const blk_t *__restrict__ base /*[tr*depth+d][2]*/,
                                  blk_t delta, uint32_t parts, uint32_t depth, blk_t *__restrict__ tg_sums,
                                  blk_t *__restrict__ tg_last) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
     if (tr >= parts) return;
@@ -191,7 +191,7 @@ __global__ void k_recv_fix(const blk_t *__restrict__ base, const uint8_t *__rest
 __global__ void k_recv_last(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
                             const blk_t *__restrict__ tg_last, const blk_t *__restrict__ my_sums /*level depth-1*/,
                             uint32_t parts, uint32_t depth, uint64_t cols, blk_t *__restrict__ V) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
     if (tr >= parts) return;
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(128)
 // ------------------------------------------------------------------------------------------------
 // hashes (silent_ot/mod.rs:275-287, 470-482) and MT bits (gmw/src/mul_triple/silent_ot.rs:93-111)
 __global__ void k_sender_hash(const blk_t *__restrict__ B, blk_t delta, uint64_t n, blk_t *__restrict__ out) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     blk_t d = delta;
     d.x &= ~1u;
@@ -258,7 +258,7 @@ __global__ void k_sender_hash(const blk_t *__restrict__ B, blk_t delta, uint64_t
 
 __global__ void k_receiver_hash(const blk_t *__restrict__ A, uint64_t n, blk_t *__restrict__ out,
                                 uint64_t *__restrict__ choice_words) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     const uint64_t n_pad = (n + 63) & ~63ull;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
@@ -274,7 +274,7 @@ __global__ void k_receiver_hash(const blk_t *__restrict__ A, uint64_t n, blk_t *
 // a = lsb(A); b = lsb(m0)^lsb(m1); v = lsb(m0); u = lsb(H(A&~1)); c = a&b ^ u ^ v
 __global__ void k_mt_bits(const blk_t *__restrict__ B, const blk_t *__restrict__ A, blk_t delta, uint64_t n,
                           uint64_t *__restrict__ wa, uint64_t *__restrict__ wb, uint64_t *__restrict__ wc) {
-    __shared__ uint32_t te[4][256];
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
     blk_t d = delta;
     d.x &= ~1u;
