@@ -180,6 +180,24 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// four rows at a time: the conversion acts identically on every row, so the LDS kernels move 16-byte quads
+struct u4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ u4 operator^(u4 a, u4 b) { return {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
+__device__ __forceinline__ u4 operator|(u4 a, u4 b) { return {a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w}; }
+__device__ __forceinline__ u4 operator&(u4 a, uint32_t m) { return {a.x & m, a.y & m, a.z & m, a.w & m}; }
+__device__ __forceinline__ u4 operator>>(u4 a, uint32_t s) { return {a.x >> s, a.y >> s, a.z >> s, a.w >> s}; }
+__device__ __forceinline__ u4 operator<<(u4 a, uint32_t s) { return {a.x << s, a.y << s, a.z << s, a.w << s}; }
+__device__ __forceinline__ u4 &operator^=(u4 &a, u4 b) {
+    a = a ^ b;
+    return a;
+}
+__device__ __forceinline__ u4 &operator|=(u4 &a, u4 b) {
+    a = a | b;
+    return a;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2b: all conversion phases whose chunk fits a tile of 2^tb (<= 2^16) elements, fused in LDS, in place.
 // Tile = 2^(tb-5) words x 16 rows of one plane (128 KiB at tb = 16). Each phase is split in the two
@@ -192,59 +210,60 @@ struct conv_phases {
     uint8_t lchunk[48], lpw[48];  // log2(chunk), log2(pw); half = chunk / 2
 };
 #define CT_ROWS 16
+#define CT_RQ 4  // row quads per tile
 #define CT_THREADS 1024
 
-__device__ __forceinline__ void ct_fold(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
+__device__ __forceinline__ void ct_fold(u4 *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
     const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
     const uint32_t nchunks = tile_words >> (lchunk - 5);
     if (lpw >= 5) {
         const uint32_t pw_w = 1u << (lpw - 5);
-        const uint32_t items = nchunks * pw_w * CT_ROWS;
+        const uint32_t items = nchunks * pw_w * CT_RQ;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t r = it & (CT_RQ - 1), wi = it / CT_RQ;
             uint32_t c = wi >> (lpw - 5), d = wi & (pw_w - 1);
             uint32_t base = c * chunk_w + half_w;
-            lds[(base + d) * CT_ROWS + r] ^= lds[(base + half_w - pw_w + d) * CT_ROWS + r];
+            lds[(base + d) * CT_RQ + r] ^= lds[(base + half_w - pw_w + d) * CT_RQ + r];
         }
     } else {
         const uint32_t pw = 1u << lpw;
-        const uint32_t items = nchunks * CT_ROWS;
+        const uint32_t items = nchunks * CT_RQ;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & (CT_ROWS - 1), c = it / CT_ROWS;
+            uint32_t r = it & (CT_RQ - 1), c = it / CT_RQ;
             uint32_t base = c * chunk_w + half_w;
-            lds[base * CT_ROWS + r] ^= lds[(base + half_w - 1) * CT_ROWS + r] >> (32 - pw);
+            lds[base * CT_RQ + r] ^= lds[(base + half_w - 1) * CT_RQ + r] >> (32 - pw);
         }
     }
 }
 
-__device__ __forceinline__ void ct_shift(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
+__device__ __forceinline__ void ct_shift(u4 *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw) {
     const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
-    const uint32_t items = (tile_words >> 1) * CT_ROWS;
+    const uint32_t items = (tile_words >> 1) * CT_RQ;
     if (lpw >= 5) {
         const uint32_t pw_w = 1u << (lpw - 5);
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t r = it & (CT_RQ - 1), wi = it / CT_RQ;
             uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
             if (d >= pw_w) {
                 uint32_t base = c * chunk_w;
-                lds[(base + d) * CT_ROWS + r] ^= lds[(base + half_w + d - pw_w) * CT_ROWS + r];
+                lds[(base + d) * CT_RQ + r] ^= lds[(base + half_w + d - pw_w) * CT_RQ + r];
             }
         }
     } else {
         const uint32_t pw = 1u << lpw;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & (CT_ROWS - 1), wi = it / CT_ROWS;
+            uint32_t r = it & (CT_RQ - 1), wi = it / CT_RQ;
             uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
             uint32_t base = c * chunk_w;
-            uint32_t h = lds[(base + half_w + d) * CT_ROWS + r] << pw;
-            if (d) h |= lds[(base + half_w + d - 1) * CT_ROWS + r] >> (32 - pw);
-            lds[(base + d) * CT_ROWS + r] ^= h;
+            u4 h = lds[(base + half_w + d) * CT_RQ + r] << pw;
+            if (d) h |= lds[(base + half_w + d - 1) * CT_RQ + r] >> (32 - pw);
+            lds[(base + d) * CT_RQ + r] ^= h;
         }
     }
 }
 
 // chunk <= 32: every chunk lives inside one word; combined formula on the word itself
-__device__ __forceinline__ void ct_intraword(uint32_t *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw,
+__device__ __forceinline__ void ct_intraword(u4 *lds, uint32_t tile_words, uint32_t lchunk, uint32_t lpw,
                                              bool inverse) {
     const uint32_t chunk = 1u << lchunk, pw = 1u << lpw, half = chunk >> 1, D = half - pw;
     uint32_t m1 = range_mask(half, half + pw) | range_mask(pw, half);
@@ -253,11 +272,11 @@ __device__ __forceinline__ void ct_intraword(uint32_t *lds, uint32_t tile_words,
         m1 |= m1 << s;
         m2 |= m2 << s;
     }
-    const uint32_t items = tile_words * CT_ROWS;
+    const uint32_t items = tile_words * CT_RQ;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t v = lds[it];
-        uint32_t o = v ^ ((v >> D) & m1);
-        if (2 * D < 32) o ^= (v >> (2 * D)) & m2;
+        u4 v = lds[it];
+        u4 o = v ^ ((v >> D) & m1);
+        if (2 * D < 32) o ^= ((v >> (2 * D)) & m2);
         lds[it] = o;
     }
 }
@@ -265,17 +284,17 @@ __device__ __forceinline__ void ct_intraword(uint32_t *lds, uint32_t tile_words,
 template <int NP>
 __global__ void __launch_bounds__(CT_THREADS)
     k_conv_tile(uint32_t *__restrict__ D, uint32_t tb, conv_phases ph, int inverse) {
-    __shared__ uint32_t lds[2048 * CT_ROWS];
+    __shared__ u4 lds[2048 * CT_RQ];
     const uint32_t tile_words = 1u << (tb - 5);
     // blockIdx.x = ((tile * NP) + plane) * 8 + rowgrp
     const uint32_t rowgrp = blockIdx.x & 7;
     const uint32_t plane = (blockIdx.x >> 3) % NP;
     const uint64_t tile = (blockIdx.x >> 3) / NP;
     uint32_t *g = D + (tile * tile_words * NP + plane) * ROWS + rowgrp * CT_ROWS;
-    const uint32_t items = tile_words * CT_ROWS;
+    const uint32_t items = tile_words * CT_RQ;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it & (CT_ROWS - 1), wl = it / CT_ROWS;
-        lds[it] = g[(uint64_t)wl * NP * ROWS + r];
+        uint32_t r = it & (CT_RQ - 1), wl = it / CT_RQ;
+        lds[it] = *(const u4 *)(g + (uint64_t)wl * NP * ROWS + 4 * r);
     }
     __syncthreads();
     for (int q = 0; q < ph.n; q++) {
@@ -295,8 +314,8 @@ __global__ void __launch_bounds__(CT_THREADS)
         __syncthreads();
     }
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it & (CT_ROWS - 1), wl = it / CT_ROWS;
-        g[(uint64_t)wl * NP * ROWS + r] = lds[it];
+        uint32_t r = it & (CT_RQ - 1), wl = it / CT_RQ;
+        *(u4 *)(g + (uint64_t)wl * NP * ROWS + 4 * r) = lds[it];
     }
 }
 
@@ -309,36 +328,37 @@ __global__ void __launch_bounds__(CT_THREADS)
 // most 31 bits in total, so one halo word per unit supplies every bit that crosses into the tile; its low bits
 // decay phase by phase and it is never written back.
 #define TOPK_ROWS 32
-__device__ __forceinline__ void top_fold(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
+#define TOPK_RQ 8  // row quads
+__device__ __forceinline__ void top_fold(u4 *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
                                          uint32_t lpw) {
-    const uint32_t lcr = 31 - __clz(NC * TOPK_ROWS);  // NC and TOPK_ROWS are powers of two
+    const uint32_t lcr = 31 - __clz(NC * TOPK_RQ);  // NC and TOPK_ROWS are powers of two
     const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1, nchunks = NU >> (lchunk - 16);
     if (lpw >= 16) {
         const uint32_t pw_u = 1u << (lpw - 16);
-        const uint32_t items = nchunks * pw_u * NC * TOPK_ROWS;
+        const uint32_t items = nchunks * pw_u * NC * TOPK_RQ;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
             uint32_t cr = it & ((1u << lcr) - 1), uj = it >> lcr;
             uint32_t c = uj >> (lpw - 16), j = uj & (pw_u - 1);
             uint32_t ud = c * chunk_u + half_u + j, us = ud + half_u - pw_u;
-            lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
+            lds[ud * NC * TOPK_RQ + cr] ^= lds[us * NC * TOPK_RQ + cr];
         }
     } else if (wrap) {
         const uint32_t pw = 1u << lpw;
-        const uint32_t items = nchunks * TOPK_ROWS;
+        const uint32_t items = nchunks * TOPK_RQ;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it % TOPK_ROWS, c = it / TOPK_ROWS;
+            uint32_t r = it % TOPK_RQ, c = it / TOPK_RQ;
             uint32_t ud = c * chunk_u + half_u, us = c * chunk_u + chunk_u - 1;
-            lds[(ud * NC + 1) * TOPK_ROWS + r] ^= lds[(us * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+            lds[(ud * NC + 1) * TOPK_RQ + r] ^= lds[(us * NC + 0) * TOPK_RQ + r] >> (32 - pw);
         }
     }
 }
 
-__device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
+__device__ __forceinline__ void top_shift(u4 *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
                                           uint32_t lpw) {
-    const uint32_t lcr = 31 - __clz(NC * TOPK_ROWS);
+    const uint32_t lcr = 31 - __clz(NC * TOPK_RQ);
     const uint32_t lhalf = lchunk - 17;
     const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1;
-    const uint32_t items = (NU / 2) * NC * TOPK_ROWS;
+    const uint32_t items = (NU / 2) * NC * TOPK_RQ;
     if (lpw >= 16) {
         const uint32_t pw_u = 1u << (lpw - 16);
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
@@ -346,25 +366,25 @@ __device__ __forceinline__ void top_shift(uint32_t *lds, uint32_t NU, uint32_t N
             uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
             if (d >= pw_u) {
                 uint32_t ud = c * chunk_u + d, us = c * chunk_u + half_u + d - pw_u;
-                lds[ud * NC * TOPK_ROWS + cr] ^= lds[us * NC * TOPK_ROWS + cr];
+                lds[ud * NC * TOPK_RQ + cr] ^= lds[us * NC * TOPK_RQ + cr];
             }
         }
     } else {
         const uint32_t pw = 1u << lpw;
         for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), ui = it >> lcr;
+            uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), ui = it >> lcr;
             uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
             uint32_t ud = c * chunk_u + d, us = ud + half_u;
-            uint32_t h = lds[(us * NC + col) * TOPK_ROWS + r] << pw;
+            u4 h = lds[(us * NC + col) * TOPK_RQ + r] << pw;
             if (col >= 2) {
-                h |= lds[(us * NC + col - 1) * TOPK_ROWS + r] >> (32 - pw);
+                h |= lds[(us * NC + col - 1) * TOPK_RQ + r] >> (32 - pw);
             } else if (col == 1) {
                 if (!wrap)
-                    h |= lds[(us * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+                    h |= lds[(us * NC + 0) * TOPK_RQ + r] >> (32 - pw);
                 else if (d != 0)  // offset 0: the preceding word is offset 2047 of the previous unit
-                    h |= lds[((us - 1) * NC + 0) * TOPK_ROWS + r] >> (32 - pw);
+                    h |= lds[((us - 1) * NC + 0) * TOPK_RQ + r] >> (32 - pw);
             }
-            lds[(ud * NC + col) * TOPK_ROWS + r] ^= h;
+            lds[(ud * NC + col) * TOPK_RQ + r] ^= h;
         }
     }
 }
@@ -373,7 +393,7 @@ template <int NP>
 __global__ void __launch_bounds__(CT_THREADS)
     k_conv_top(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, uint32_t lnu, uint32_t lnc,
                conv_phases ph, int inverse) {
-    __shared__ uint32_t lds[32768 + 1024];
+    __shared__ u4 lds[8192 + 256];
     const uint32_t NU = 1u << lnu, NC = 1u << lnc;
     const uint32_t W = NC - 1;  // payload columns
     // blockIdx.x = ((colblock * NP) + plane) * 4 + rowgrp
@@ -385,12 +405,12 @@ __global__ void __launch_bounds__(CT_THREADS)
     // out of place: neighbouring tiles read each other's edge words as halos
     const uint32_t *g = Din + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
     uint32_t *go = Dout + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
-    const uint32_t items = NU * NC * TOPK_ROWS;
+    const uint32_t items = NU * NC * TOPK_RQ;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), u = it >> (lnc + 5);
+        uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), u = it >> (lnc + 3);
         uint32_t o = col ? o0 + col - 1 : (wrap ? 2047u : o0 - 1);
-        uint32_t v = 0;
-        if (o < 2048) v = g[((uint64_t)u * 2048 + o) * NP * ROWS + r];
+        u4 v = {0, 0, 0, 0};
+        if (o < 2048) v = *(const u4 *)(g + ((uint64_t)u * 2048 + o) * NP * ROWS + 4 * r);
         lds[it] = v;
     }
     __syncthreads();
@@ -409,10 +429,10 @@ __global__ void __launch_bounds__(CT_THREADS)
         __syncthreads();
     }
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_ROWS, col = (it / TOPK_ROWS) & (NC - 1), u = it >> (lnc + 5);
+        uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), u = it >> (lnc + 3);
         if (col == 0) continue;
         uint32_t o = o0 + col - 1;
-        if (o < 2048) go[((uint64_t)u * 2048 + o) * NP * ROWS + r] = lds[it];
+        if (o < 2048) *(u4 *)(go + ((uint64_t)u * 2048 + o) * NP * ROWS + 4 * r) = lds[it];
     }
 }
 
