@@ -1186,7 +1186,7 @@ static void conv_rec(std::vector<phase_t> &ph, uint32_t nbits, uint64_t unit) {
     conv_rec(ph, qb, unit);
 }
 
-static inline unsigned gridn(uint64_t n, unsigned block, unsigned cap = 65535u * 16) {
+static inline unsigned gridn(uint64_t n, unsigned block, unsigned cap = 0x7fffffffu) {
     uint64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
     return (unsigned)(g > cap ? cap : g);

@@ -135,3 +135,49 @@ def test_2pow22_encode_matches_oracle_with_reference_multiplier(orc):
         assert np.array_equal(eng.qc_dual_encode_host(0, rT), want)
     finally:
         eng.close()
+
+
+def _encode_both_vs_oracle(orc, n, T, seed, receiver=True):
+    import flute_amd as fa
+    conf = orc.configure(n)
+    rng = np.random.default_rng(seed)
+    msg2, msg, choices = orc.fake_base(conf, rng)
+    delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    prg = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    eng = fa.Engine(n)
+    try:
+        sums, last = eng.sender_expand(msg2, delta, prg, T)
+        eng.qc_encode(0)
+        B = eng.download_encoded(0)
+        pts = eng.points(choices)
+        if receiver:
+            eng.receiver_expand(msg, choices, sums, last)
+            eng.qc_encode(1, pts)
+            A = eng.download_encoded(1)
+    finally:
+        eng.close()
+    orc.use_reference_multiplier(True)
+    try:
+        o_rT, o_sums, o_last = orc.pprf_sender_expand(conf, msg2, delta, prg, T)
+        assert np.array_equal(sums, o_sums) and np.array_equal(last, o_last)
+        assert np.array_equal(B, orc.qc_dual_encode(conf, o_rT))
+        if receiver:
+            o_rT_r = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
+            o_A, _ = orc.qc_dual_encode2(conf, o_rT_r, pts, packed=True)
+            assert np.array_equal(A, o_A)
+    finally:
+        orc.use_reference_multiplier(False)
+
+
+@pytest.mark.parametrize("n,T", [(2000000, 4), (3 * 2 ** 20 + 12345, 7), (100003, 3)])
+def test_odd_sizes_match_oracle(orc, n, T):
+    """bench's default --ots 2 000 000 (bench.rs:55-56; P < FFT capacity, no tail terms) and non-power-of-two n."""
+    _encode_both_vs_oracle(orc, n, T, n % 9973)
+
+
+def test_2pow26_sender_matches_oracle(orc):
+    """BASELINE.json's largest size: 2^26 OTs (FFT of 2^23 points, twiddles outside GF(2^16), generic
+    conversion path). Needs oracle/_ref for a tolerable oracle run time."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref absent")
+    _encode_both_vs_oracle(orc, 1 << 26, 4, 26, receiver=False)
