@@ -25,8 +25,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 QC_BYTES_PER_OT = 48.0  # 32 B read (rT) + 16 B write per requested OT
-QC_KERNELS = ("k_clear_lsb", "k_qc_load", "k_conv_phase16", "k_qc_expand", "k_fft_level", "k_fft_low_mul",
-              "k_ifft_level", "k_qc_unpack", "k_conv_phase32", "k_qc_store", "k_qc_final", "k_conv_tile16", "k_conv_tile32")
+QC_KERNELS = ("k_clear_lsb", "k_qc_load", "k_conv_fwd", "k_conv_fwd_tile", "k_fft_top", "k_fft_mid", "k_fft_low_mul",
+              "k_ifft_mid", "k_ifft_top", "k_conv_inv_tile", "k_conv_inv", "k_qc_store", "k_qc_final")
 
 
 def cpu_baseline(log2n_sample, T):

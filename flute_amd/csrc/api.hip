@@ -32,8 +32,8 @@ extern "C" int sot_device_count(void) {
 const char *const SOT_KID_NAMES[KID_COUNT] = {
     "k_roots",       "k_ggm_level",     "k_ggm_leaf", "k_sender_treegrp", "k_recv_init",  "k_recv_fix",
     "k_recv_last",   "k_transpose_tiles", "k_sender_hash", "k_receiver_hash", "k_mt_bits",  "k_clear_lsb",
-    "k_qc_load",     "k_conv_phase16",  "k_qc_expand", "k_fft_level",     "k_fft_low_mul", "k_ifft_level",
-    "k_qc_unpack",   "k_conv_phase32",  "k_qc_store",  "k_qc_final", "k_conv_tile16", "k_conv_tile32"};
+    "k_qc_load",     "k_conv_fwd",      "k_conv_fwd_tile", "k_fft_top",     "k_fft_mid",    "k_fft_low_mul",
+    "k_ifft_mid",    "k_ifft_top",      "k_conv_inv_tile", "k_conv_inv",    "k_qc_store",   "k_qc_final"};
 
 static hipEvent_t prof_event(sot_ctx *c) {
     if (!c->prof_free.empty()) {
@@ -339,6 +339,13 @@ extern "C" int sot_qc_dual_encode_host(sot_ctx *c, int role, const void *rT, con
     if (blocks_out) SOT_TRY(sot_download_encoded(c, role, blocks_out));
     return SOT_OK;
 }
+
+extern "C" int sot_qc_transform_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out) {
+    CHECK_CTX(c);
+    if (!row_in || !row_out || stage < 0 || stage > 4) return SOT_EINVAL;
+    return qc_debug_row(c, row_in, stage, row_out);
+}
+extern "C" uint32_t sot_qc_log2_capacity(const sot_ctx *c) { return c ? c->g.m : 0; }
 
 extern "C" int sot_sender_hash(sot_ctx *c, const void *delta, void *msgs_out) {
     CHECK_CTX(c);

@@ -4,14 +4,19 @@
 // a * b1_r via bitpolymul's additive FFT over GF(2^128), + b0_r, modp, 128x128 transposes).
 //
 // MI355X formulation: the 128 rows multiply by the same public a, and a Block of the untransposed
-// PPRF output V holds one coefficient of all 128 row polynomials, so the rows are processed bit-sliced
-// (lane = row, bit = 32 consecutive FFT points) and every field operation is an XOR/AND network:
-//   V1 -> 16 bit planes (Kronecker x -> g, 16 bits per element) -> monomial-to-novel basis conversion
-//   -> GF(2^32) (nimber) coordinates, 32 planes -> LCH additive FFT butterflies with Cantor-basis points
-//   -> pointwise multiply by FFT(a) (precomputed bit matrices) -> inverse butterflies -> inverse basis
-//   conversion -> overlap-add back to Blocks T -> fold mod x^P - 1 together with V0 and the short
-//   schoolbook "tail" terms for the few bits of a and V1 above the power-of-two FFT capacity.
-// The math (and the generators of the constant tables) is in gf2fft_model.py / gen_tables.py.
+// PPRF output V holds one coefficient of all 128 row polynomials, so the rows are processed bit-sliced:
+// Z[w][row] is a 32-bit word holding coefficients 32w .. 32w+31 of row `row` (512 B "granule" per w).
+// The product is a Frobenius-pruned additive FFT over GF(2^32) (nimbers, Cantor-basis points), executed
+// IN PLACE on Z from the first basis-conversion pass to the last:
+//   f in GF(2)[x], deg f < 2^m, is determined by its values on the coset beta_m + W_m; squaring permutes the
+//   coset with orbits of size 32 and f(w^2) = f(w)^2, so one value per orbit is enough, and
+//   {index bits m-1, m-2, m-4, m-8, m-16 = 0} is a cross-section. The Lin-Chung-Han butterfly network
+//   therefore drops the "bit = 1" branch at levels r = m - i in {1, 2, 4, 8, 16}. At such a level the kept branch
+//   is x + tau y with x, y in GF(2^r) and tau = 2^r + tau_lo (nimber), i.e. (x + tau_lo y) | (y << r): the
+//   values double in width in place, and word-index bit b(r) = m - r - 5 becomes bit log2(r) of the plane
+//   (nimber coordinate) index. The data stay at 2^m bits per row throughout (no Kronecker padding).
+// Every field operation is a GF(2)-linear map on planes: v_bitop3 (a ^ (b & mask)) with wave-uniform masks.
+// The math, in this exact layout, is executable in fafft_model.py (and gf2fft_model.py / gen_tables.py).
 #include <stdlib.h>
 #include <string.h>
 
@@ -19,7 +24,7 @@
 
 #include "sot_internal.h"
 
-#define ROWS 128  // bit rows of a Block; lane l of a wave owns rows l and l + 64
+#define ROWS 128  // bit rows of a Block
 
 static __device__ const uint32_t d_BETA[32] = {
 #include "qc_beta.inc"
@@ -76,56 +81,85 @@ __global__ void k_set_points(blk_t *__restrict__ V, const uint64_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: Blocks -> 16 bit planes. X[(w*16 + t)*ROWS + row] bit p = bit `row` of V1'[16*(32 w + p) + t],
-// V1'[c] = V1[c] ^ V1[c + P] (reduction mod x^P - 1 of the 2*n_blocks*128-bit row), c < lo_bits.
-// One wave per word index w (512 Blocks in, 8 KiB out).
+// K1: Blocks -> row words. Z[w * ROWS + row] bit p = bit `row` of V1'[32 w + p],
+// V1'[c] = V1[c] ^ V1[c + P] (reduction mod x^P - 1 of the 2*n_blocks*128-bit row), c < lo_bits; zero above.
+// One workgroup per 64 words (2048 Blocks in, 32 KiB out); both sides coalesced through LDS.
+#define LD_W 64
 __global__ void __launch_bounds__(256)
-    k_qc_load(const blk_t *__restrict__ V1, uint64_t v1_len, uint64_t P, uint64_t lo_bits, uint64_t nw_in,
-              uint32_t *__restrict__ X) {
-    __shared__ uint32_t tile[4][512 * 4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
-    if (w < nw_in) {
-        for (uint32_t i = lane; i < 512; i += 64) {
-            uint64_t c = w * 512 + i;
-            blk_t v = make_uint4(0, 0, 0, 0);
-            if (c < lo_bits) {
-                v = V1[c];
-                if (c + P < v1_len) {
-                    blk_t u = V1[c + P];
-                    v.x ^= u.x;
-                    v.y ^= u.y;
-                    v.z ^= u.z;
-                    v.w ^= u.w;
-                }
+    k_qc_load(const blk_t *__restrict__ V1, uint64_t v1_len, uint64_t P, uint64_t lo_bits, uint64_t nw_half,
+              uint32_t *__restrict__ Z) {
+    __shared__ uint32_t tin[LD_W * 132];   // [w][p][q] words, 132-word stride: conflict-free column reads
+    __shared__ uint32_t tout[LD_W * 129];  // [w][row]
+    const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
+    for (uint32_t i = threadIdx.x; i < LD_W * 32; i += 256) {
+        const uint64_t c = w0 * 32 + i;
+        blk_t v = make_uint4(0, 0, 0, 0);
+        if (c < lo_bits) {
+            v = V1[c];
+            if (c + P < v1_len) {
+                blk_t u = V1[c + P];
+                v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
             }
-            *(blk_t *)&tile[wave][i * 4] = v;
         }
+        uint32_t *d = tin + (i >> 5) * 132 + (i & 31) * 4;
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     }
     __syncthreads();
-    if (w >= nw_in) return;
-    const uint32_t t = lane >> 2, q = lane & 3;
-    uint32_t a[32];
+    {
+        const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
+        uint32_t a[32];
 #pragma unroll
-    for (int p = 0; p < 32; p++) a[p] = tile[wave][(16 * p + t) * 4 + q];
-    transpose32(a);
-    uint32_t *dst = X + (w * 16 + t) * ROWS + 32 * q;
+        for (int p = 0; p < 32; p++) a[p] = tin[wl * 132 + p * 4 + q];
+        transpose32(a);
 #pragma unroll
-    for (int b = 0; b < 32; b++) dst[b] = a[b];
+        for (int b = 0; b < 32; b++) tout[wl * 129 + 32 * q + b] = a[b];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += 256) {
+        const uint64_t w = w0 + (i >> 7);
+        if (w < nw_half) Z[w * ROWS + (i & 127)] = tout[(i >> 7) * 129 + (i & 127)];
+    }
 }
 
-// public polynomial: row 0 of the plane layout from a packed bit vector, other rows zero (memset before)
-__global__ void k_a_load(const uint32_t *__restrict__ abits, uint64_t nbits, uint64_t nw_in, uint32_t *__restrict__ X) {
-    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (w, t)
-    if (idx >= nw_in * 16) return;
-    uint64_t w = idx >> 4;
-    uint32_t t = idx & 15;
-    uint32_t word = 0;
-    for (uint32_t p = 0; p < 32; p++) {
-        uint64_t bit = 16 * (32 * w + p) + t;
-        if (bit < nbits) word |= ((abits[bit >> 5] >> (bit & 31)) & 1u) << p;
+// public polynomial: row 0 from a packed bit vector (other rows zeroed by the caller)
+__global__ void k_a_load(const uint32_t *__restrict__ abits, uint64_t nbits, uint64_t nw_half, uint32_t *__restrict__ Z) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw_half) return;
+    uint32_t v = 0;
+    if (32 * w < nbits) {
+        v = abits[w];
+        if (nbits - 32 * w < 32) v &= (1u << (nbits - 32 * w)) - 1u;
     }
-    X[(w * 16 + t) * ROWS] = word;
+    Z[w * ROWS] = v;
+}
+
+// K9: row words -> Blocks: T[32 w + p] bit row = Z[w][row] bit p.
+__global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ Z, uint64_t nw, blk_t *__restrict__ T) {
+    __shared__ uint32_t tin[LD_W * 129];   // [w][row]
+    __shared__ uint32_t tout[LD_W * 132];  // [w][p][q]
+    const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
+    for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += 256) {
+        const uint64_t w = w0 + (i >> 7);
+        tin[(i >> 7) * 129 + (i & 127)] = w < nw ? Z[w * ROWS + (i & 127)] : 0u;
+    }
+    __syncthreads();
+    {
+        const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
+        uint32_t a[32];
+#pragma unroll
+        for (int b = 0; b < 32; b++) a[b] = tin[wl * 129 + 32 * q + b];
+        transpose32(a);
+#pragma unroll
+        for (int p = 0; p < 32; p++) tout[wl * 132 + p * 4 + q] = a[p];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LD_W * 32; i += 256) {
+        const uint64_t c = w0 * 32 + i;
+        if (c < nw * 32) {
+            const uint32_t *s = tout + (i >> 5) * 132 + (i & 31) * 4;
+            T[c] = make_uint4(s[0], s[1], s[2], s[3]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -437,14 +471,15 @@ __global__ void __launch_bounds__(CT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
-// twiddle matrices. TW[tbl][idx][k] = row k of "multiply by point(2 * (idx << 10 tbl))";
-// TWC[tbl][idx] = that point. Rows/points of a block index j are the XOR over tbl of entry (j >> 10 tbl) & 1023.
-#define TW_TABLES 3
+// twiddle matrices. TW[tbl][e][k] = row k (bit j set <=> output coordinate k takes input coordinate j) of
+// "multiply by point(e << 8 tbl)", e < 256, tbl < 4; TWC[tbl][e] = that point. point() is GF(2)-linear, so the
+// rows / the element of any index q are the XOR over tbl of the entries of q's bytes.
+#define TW_TABLES 4
 __global__ void k_build_tw(uint32_t *__restrict__ TW, uint32_t *__restrict__ TWC) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (tbl, e, k)
-    if (idx >= TW_TABLES * 1024 * 32) return;
-    uint32_t k = idx & 31, e = (idx >> 5) & 1023, tbl = idx >> 15;
-    uint64_t p = 2ull * ((uint64_t)e << (10 * tbl));
+    if (idx >= TW_TABLES * 256 * 32) return;
+    uint32_t k = idx & 31, e = (idx >> 5) & 255, tbl = idx >> 13;
+    uint32_t p = e << (8 * tbl);
     uint32_t c = 0;
     for (int i = 0; i < 32; i++)
         if ((p >> i) & 1) c ^= d_BETA[i];
@@ -452,498 +487,189 @@ __global__ void k_build_tw(uint32_t *__restrict__ TW, uint32_t *__restrict__ TWC
     for (int t = 0; t < 32; t++)
         if ((c >> t) & 1) row ^= d_RTAB[t * 32 + k];
     TW[idx] = row;
-    if (k == 0) TWC[tbl * 1024 + e] = c;
+    if (k == 0) TWC[tbl * 256 + e] = c;
 }
 
-struct twid {
-    uint32_t c;        // the field element (nimber)
-    uint32_t row[32];  // row k: bit j set <=> output bit k takes input bit j
+// rows k0 .. k0+N-1 of the matrix of point(q); q and k0 are wave-uniform: everything stays in SGPRs
+template <int N>
+__device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_t q, uint32_t k0, uint32_t rows[N]) {
+    const uint32_t *t0 = TW + ((q & 255) << 5) + k0;
+    const uint32_t *t1 = TW + ((256 + ((q >> 8) & 255)) << 5) + k0;
+    const uint32_t *t2 = TW + ((512 + ((q >> 16) & 255)) << 5) + k0;
+    const uint32_t *t3 = TW + ((768 + (q >> 24)) << 5) + k0;
+#pragma unroll
+    for (int k = 0; k < N; k++) rows[k] = t0[k] ^ t1[k] ^ t2[k] ^ t3[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiles. A workgroup gathers 2^nb granules (x 64 rows) whose word indices differ in the nb bits pos[0..nb),
+// runs some butterfly levels on them in LDS and scatters them back. Tile bit j <-> word-index bit pos[j]; the
+// plane bits come first (tile bit t = plane-index bit t for every pruned level already passed), so the K = 2^np
+// planes of a value are K consecutive LDS slots.
+struct tile_desc {
+    uint32_t m;      // log2 capacity
+    uint32_t nb;     // tile bits
+    uint32_t tmask;  // word-index bits that belong to the tile
+    uint32_t pmw;    // word-index bits of the pruned levels
+    uint32_t zero_bit;  // tile bit whose "1" half is known to be zero on input (forward transform of an operand); 32 = none
+    uint32_t nlev;
+    uint8_t pos[12];
+    uint8_t lev_r[8], lev_tbit[8], lev_np[8], lev_pruned[8];
 };
 
-__device__ __forceinline__ void load_twid(const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC, uint32_t j,
-                                          twid &tw) {
-    // j is wave-uniform: everything below lives in SGPRs
-    const uint32_t e0 = j & 1023, e1 = (j >> 10) & 1023, e2 = (j >> 20) & 1023;
-    tw.c = TWC[e0] ^ TWC[1024 + e1] ^ TWC[2048 + e2];
-#pragma unroll
-    for (int k = 0; k < 32; k++)
-        tw.row[k] = TW[e0 * 32 + k] ^ TW[(1024 + e1) * 32 + k] ^ TW[(2048 + e2) * 32 + k];
+__device__ __forceinline__ uint32_t tile_base(const tile_desc &d, uint32_t o) {
+    uint32_t w = 0;
+    for (uint32_t b = 0; b + 5 < d.m; b++)
+        if (!((d.tmask >> b) & 1u)) {
+            w |= (o & 1u) << b;
+            o >>= 1;
+        }
+    return w;
+}
+__device__ __forceinline__ uint32_t tile_word(const tile_desc &d, uint32_t t) {
+    uint32_t w = 0;
+    for (uint32_t j = 0; j < d.nb; j++) w |= ((t >> j) & 1u) << d.pos[j];
+    return w;
 }
 
-// t = c (x) y on two independent bit-sliced operands (rows l and l+64); the matrix is block diagonal
-// with identical BxB blocks when c lies in the subfield GF(2^B)
-template <int B>
-__device__ __forceinline__ void mul_blocks(const twid &tw, const uint32_t y0[32], const uint32_t y1[32], uint32_t t0[32],
-                                           uint32_t t1[32]) {
-    // KB outputs at a time, input index outermost: 2*KB independent accumulation chains in flight
-    constexpr int KB = 4;
+#define TL_ROWS 64
+#define TL_THREADS 1024
+#define TL_WAVES (TL_THREADS / 64)
+
+__device__ __forceinline__ void tile_load(uint32_t *lds, const uint32_t *__restrict__ Z, const tile_desc &d,
+                                          uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
+    const uint32_t nslots = 1u << d.nb;
+    for (uint32_t s = wave; s < nslots; s += TL_WAVES) {
+        uint32_t v = 0;
+        if (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u))
+            v = Z[(uint64_t)(base_w | tile_word(d, s)) * ROWS + rh * TL_ROWS + lane];
+        lds[s * TL_ROWS + lane] = v;
+    }
+}
+__device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__restrict__ Z, const tile_desc &d,
+                                           uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
+    const uint32_t nslots = 1u << d.nb;
+    for (uint32_t s = wave; s < nslots; s += TL_WAVES)
+        Z[(uint64_t)(base_w | tile_word(d, s)) * ROWS + rh * TL_ROWS + lane] = lds[s * TL_ROWS + lane];
+}
+
+// one work item of a butterfly level: outputs c0 .. c0+NO-1 (NO = min(K, 8)) of the butterfly whose x planes sit in
+// slots xs .. xs+K-1 and y planes in ys .. ys+K-1.
+//   forward: x ^= tau y; y ^= x      inverse: y ^= x; x ^= tau y      pruned (both ways): x ^= tau_lo y
+// Results are returned in registers; the caller writes them after a barrier (other waves read the same slots).
+template <int K, bool INV>
+__device__ __forceinline__ void bfly_item(const uint32_t *lds, uint32_t xs, uint32_t ys, const uint32_t *__restrict__ TW,
+                                          uint32_t q, uint32_t c0, bool pruned, uint32_t lane, uint32_t xn[8],
+                                          uint32_t yn[8]) {
+    constexpr int NO = K < 8 ? K : 8;
+    uint32_t rows[NO];
+    tw_rows<NO>(TW, q, c0, rows);
+    uint32_t y[K];
 #pragma unroll
-    for (int blk = 0; blk < 32 / B; blk++) {
+    for (int j = 0; j < K; j++) y[j] = lds[(ys + j) * TL_ROWS + lane];
+    if (INV && !pruned) {
 #pragma unroll
-        for (int k0 = 0; k0 < B; k0 += KB) {
-            uint32_t a0[KB], a1[KB];
+        for (int j = 0; j < K; j++) y[j] ^= lds[(xs + j) * TL_ROWS + lane];
+    }
+    uint32_t acc[NO];
 #pragma unroll
-            for (int kk = 0; kk < KB; kk++) a0[kk] = a1[kk] = 0;
+    for (int kk = 0; kk < NO; kk++) acc[kk] = lds[(xs + c0 + kk) * TL_ROWS + lane];
 #pragma unroll
-            for (int j = 0; j < B; j++) {
+    for (int j = 0; j < K; j++) {
 #pragma unroll
-                for (int kk = 0; kk < KB; kk++) {
-                    const uint32_t m = 0u - ((tw.row[k0 + kk] >> j) & 1u);  // wave-uniform: s_bfe_i32
-                    a0[kk] = XAND(a0[kk], y0[blk * B + j], m);
-                    a1[kk] = XAND(a1[kk], y1[blk * B + j], m);
+        for (int kk = 0; kk < NO; kk++) acc[kk] = XAND(acc[kk], y[j], 0u - ((rows[kk] >> j) & 1u));
+    }
+#pragma unroll
+    for (int kk = 0; kk < NO; kk++) xn[kk] = acc[kk];
+    if (!pruned) {
+        // y chunk: re-read (dynamic register indexing would spill)
+#pragma unroll
+        for (int kk = 0; kk < NO; kk++) {
+            uint32_t yc = lds[(ys + c0 + kk) * TL_ROWS + lane];
+            if (INV)
+                yn[kk] = yc ^ lds[(xs + c0 + kk) * TL_ROWS + lane];
+            else
+                yn[kk] = yc ^ xn[kk];
+        }
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, uint32_t base_w,
+                                            const uint32_t *__restrict__ TW, uint32_t wave, uint32_t lane) {
+    for (uint32_t qi = 0; qi < d.nlev; qi++) {
+        const uint32_t L = INV ? d.nlev - 1 - qi : qi;
+        const uint32_t r = d.lev_r[L], tbit = d.lev_tbit[L], np = d.lev_np[L];
+        const bool pruned = d.lev_pruned[L] != 0;
+        const uint32_t K = 1u << np;
+        const uint32_t lnch = K > 8 ? np - 3 : 0;  // log2(output chunks per butterfly)
+        const uint32_t nitems = (1u << (d.nb - 1 - np)) << lnch;
+        const uint32_t NO = K < 8 ? K : 8;
+        for (uint32_t it0 = 0; it0 < nitems; it0 += TL_WAVES) {
+            const uint32_t it = it0 + wave;
+            const bool act = it < nitems;
+            uint32_t xn[8], yn[8];
+            uint32_t xs = 0, ys = 0, c0 = 0;
+            if (act) {
+                uint32_t bf = it >> lnch;
+                c0 = (it & ((1u << lnch) - 1u)) << 3;
+                uint32_t s = 0;
+                for (uint32_t j = np; j < d.nb; j++)
+                    if (j != tbit) {
+                        s |= (bf & 1u) << j;
+                        bf >>= 1;
+                    }
+                xs = s;
+                ys = s | (1u << tbit);
+                const uint32_t w = base_w | tile_word(d, s);
+                const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
+                switch (np) {
+                    case 2: bfly_item<4, INV>(lds, xs, ys, TW, q, c0, pruned, lane, xn, yn); break;
+                    case 3: bfly_item<8, INV>(lds, xs, ys, TW, q, c0, pruned, lane, xn, yn); break;
+                    case 4: bfly_item<16, INV>(lds, xs, ys, TW, q, c0, pruned, lane, xn, yn); break;
+                    default: bfly_item<32, INV>(lds, xs, ys, TW, q, c0, pruned, lane, xn, yn); break;
                 }
             }
+            __syncthreads();
+            if (act) {
 #pragma unroll
-            for (int kk = 0; kk < KB; kk++) {
-                t0[blk * B + k0 + kk] = a0[kk];
-                t1[blk * B + k0 + kk] = a1[kk];
+                for (int kk = 0; kk < 8; kk++)
+                    if (kk < (int)NO) {
+                        lds[(xs + c0 + kk) * TL_ROWS + lane] = xn[kk];
+                        if (!pruned) lds[(ys + c0 + kk) * TL_ROWS + lane] = yn[kk];
+                    }
             }
+            __syncthreads();
         }
     }
 }
 
-__device__ __forceinline__ void mul_uniform(const twid &tw, const uint32_t y0[32], const uint32_t y1[32], uint32_t t0[32],
-                                            uint32_t t1[32]) {
-    const uint32_t c = tw.c;
-    if (c < (1u << 8)) {
-        mul_blocks<8>(tw, y0, y1, t0, t1);
-    } else if (c < (1u << 16)) {
-        mul_blocks<16>(tw, y0, y1, t0, t1);
-    } else {
-        mul_blocks<32>(tw, y0, y1, t0, t1);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: Kronecker pack (16 polynomial-coefficient planes -> 32 nimber-coordinate planes, element = sum b_t g^t)
-// fused with butterfly level ell-1, whose upper input half is zero (twiddle point(0) = 0): both halves = x.
-__global__ void __launch_bounds__(256)
-    k_qc_expand(const uint32_t *__restrict__ X, uint32_t *__restrict__ D, uint64_t nw_in) {
-    static constexpr uint32_t GROW[32] = {
-#include "qc_grow.inc"
-    };
-    const uint64_t total = nw_in * ROWS;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t w = idx / ROWS;
-        const uint32_t row = idx % ROWS;
-        uint32_t x[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) x[t] = X[(w * 16 + t) * ROWS + row];
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            uint32_t y = 0;
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-                if ((GROW[k] >> t) & 1) y ^= x[t];
-            D[(w * 32 + k) * ROWS + row] = y;
-            D[((w + nw_in) * 32 + k) * ROWS + row] = y;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4: one butterfly level i >= 5 (pairs of words at distance 2^(i-5)), forward:  x ^= tw*y; y ^= x
-//                                                                        inverse:  y ^= x; x ^= tw*y
-// One wave per word pair; lane l handles rows l and l+64.
-template <bool INV>
-__global__ void __launch_bounds__(256)
-    k_fft_level(uint32_t *__restrict__ D, uint64_t npairs, uint32_t d /* = i - 5 */, const uint32_t *__restrict__ TW,
-                const uint32_t *__restrict__ TWC) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint64_t pi = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pi >= npairs) return;
-    pi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pi >> 32)) << 32) |
-         __builtin_amdgcn_readfirstlane((uint32_t)pi);
-    const uint64_t w0 = ((pi >> d) << (d + 1)) | (pi & (((uint64_t)1 << d) - 1));
-    const uint64_t w1 = w0 + ((uint64_t)1 << d);
-    const uint32_t j = (uint32_t)(pi >> d);
-    twid tw;
-    load_twid(TW, TWC, j, tw);
-    uint32_t *px = D + w0 * 32 * ROWS + lane;
-    uint32_t *py = D + w1 * 32 * ROWS + lane;
-    uint32_t x0[32], x1[32], y0[32], y1[32], t0[32], t1[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        x0[k] = px[k * ROWS];
-        x1[k] = px[k * ROWS + 64];
-        y0[k] = py[k * ROWS];
-        y1[k] = py[k * ROWS + 64];
-    }
-    if (INV) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            y0[k] ^= x0[k];
-            y1[k] ^= x1[k];
-        }
-    }
-    if (tw.c != 0) {
-        mul_uniform(tw, y0, y1, t0, t1);
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            x0[k] ^= t0[k];
-            x1[k] ^= t1[k];
-        }
-    }
-    if (!INV) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            y0[k] ^= x0[k];
-            y1[k] ^= x1[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        px[k * ROWS] = x0[k];
-        px[k * ROWS + 64] = x1[k];
-        py[k * ROWS] = y0[k];
-        py[k * ROWS + 64] = y1[k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4b: up to four consecutive word-pair levels fused through LDS. Tile = 2^nlev words at word stride 2^d0
-// (levels i = 5 + d0 .. 5 + d0 + nlev - 1) x 32 planes x 64 rows = 128 KiB at nlev = 4. One wave per
-// butterfly pair and level (the twiddle is wave uniform), lane = row.
-template <int B>
-__device__ __forceinline__ void mul_blocks1(const twid &tw, const uint32_t y[32], uint32_t t[32]) {
-    constexpr int KB = 8;
-#pragma unroll
-    for (int blk = 0; blk < 32 / B; blk++) {
-#pragma unroll
-        for (int k0 = 0; k0 < B; k0 += KB) {
-            uint32_t a[KB];
-#pragma unroll
-            for (int kk = 0; kk < KB; kk++) a[kk] = 0;
-#pragma unroll
-            for (int j = 0; j < B; j++) {
-#pragma unroll
-                for (int kk = 0; kk < KB; kk++)
-                    a[kk] = XAND(a[kk], y[blk * B + j], 0u - ((tw.row[k0 + kk] >> j) & 1u));
-            }
-#pragma unroll
-            for (int kk = 0; kk < KB; kk++) t[blk * B + k0 + kk] = a[kk];
-        }
-    }
-}
-
-#define FT_ROWS 64
-#define FT_THREADS 512
-template <bool INV>
-__global__ void __launch_bounds__(FT_THREADS)
-    k_fft_tile(uint32_t *__restrict__ D, uint32_t d0, uint32_t nlev, const uint32_t *__restrict__ TW,
-               const uint32_t *__restrict__ TWC) {
-    __shared__ uint32_t lds[16 * 32 * FT_ROWS];
+// word-level butterfly passes (top / mid levels): gather, levels, scatter
+template <bool INV, int NB>
+__global__ void __launch_bounds__(TL_THREADS)
+    k_tile_fft(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW) {
+    __shared__ uint32_t lds[(1 << NB) * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nwt = 1u << nlev;
     const uint32_t rh = blockIdx.x & 1;
-    const uint64_t ti = blockIdx.x >> 1;
-    const uint64_t wbase = ((ti >> d0) << (d0 + nlev)) | (ti & (((uint64_t)1 << d0) - 1));
-    uint32_t *g = D + rh * FT_ROWS + lane;
-    // load: (wl, k) segments of 64 rows
-    for (uint32_t s = wave; s < nwt * 32; s += FT_THREADS / 64) {
-        uint32_t wl = s >> 5, k = s & 31;
-        lds[s * FT_ROWS + lane] = g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS];
-    }
+    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
+    tile_load(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
-    for (uint32_t q = 0; q < nlev; q++) {
-        const uint32_t lv = INV ? q : nlev - 1 - q;
-        for (uint32_t pr = wave; pr < nwt / 2; pr += FT_THREADS / 64) {
-            const uint32_t a = ((pr >> lv) << (lv + 1)) | (pr & ((1u << lv) - 1));
-            const uint32_t b = a + (1u << lv);
-            const uint64_t w0 = wbase + ((uint64_t)a << d0);
-            const uint32_t j = (uint32_t)(w0 >> (d0 + lv + 1));
-            twid tw;
-            load_twid(TW, TWC, j, tw);
-            uint32_t *px = lds + (a * 32) * FT_ROWS + lane;
-            uint32_t *py = lds + (b * 32) * FT_ROWS + lane;
-            uint32_t x[32], y[32], t[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                x[k] = px[k * FT_ROWS];
-                y[k] = py[k * FT_ROWS];
-            }
-            if (INV) {
-#pragma unroll
-                for (int k = 0; k < 32; k++) y[k] ^= x[k];
-            }
-            if (tw.c != 0) {
-                if (tw.c < (1u << 8))
-                    mul_blocks1<8>(tw, y, t);
-                else if (tw.c < (1u << 16))
-                    mul_blocks1<16>(tw, y, t);
-                else
-                    mul_blocks1<32>(tw, y, t);
-#pragma unroll
-                for (int k = 0; k < 32; k++) x[k] ^= t[k];
-            }
-            if (!INV) {
-#pragma unroll
-                for (int k = 0; k < 32; k++) y[k] ^= x[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                px[k * FT_ROWS] = x[k];
-                py[k * FT_ROWS] = y[k];
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t s = wave; s < nwt * 32; s += FT_THREADS / 64) {
-        uint32_t wl = s >> 5, k = s & 31;
-        g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS] = lds[s * FT_ROWS + lane];
-    }
-}
-
-// K4c: same tile, 16 waves: every butterfly is split over two waves by plane half. Valid while every twiddle of
-// the pass lies in GF(2^16) (then multiply-by-twiddle acts on planes 0..15 and 16..31 independently with the
-// same 16x16 matrix): levels i >= ell - 16. Twice the waves per SIMD of k_fft_tile at the same LDS footprint.
-#define FT2_THREADS 1024
-template <bool INV>
-__global__ void __launch_bounds__(FT2_THREADS)
-    k_fft_tile2(uint32_t *__restrict__ D, uint32_t d0, uint32_t nlev, const uint32_t *__restrict__ TW,
-                const uint32_t *__restrict__ TWC) {
-    __shared__ uint32_t lds[16 * 32 * FT_ROWS];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nwt = 1u << nlev;
-    const uint32_t rh = blockIdx.x & 1;
-    const uint64_t ti = blockIdx.x >> 1;
-    const uint64_t wbase = ((ti >> d0) << (d0 + nlev)) | (ti & (((uint64_t)1 << d0) - 1));
-    uint32_t *g = D + rh * FT_ROWS + lane;
-    for (uint32_t s = wave; s < nwt * 32; s += FT2_THREADS / 64) {
-        uint32_t wl = s >> 5, k = s & 31;
-        lds[s * FT_ROWS + lane] = g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS];
-    }
-    __syncthreads();
-    for (uint32_t q = 0; q < nlev; q++) {
-        const uint32_t lv = INV ? q : nlev - 1 - q;
-        for (uint32_t itx = wave; itx < nwt; itx += FT2_THREADS / 64) {
-            const uint32_t pr = itx >> 1, hf = itx & 1;
-            const uint32_t a = ((pr >> lv) << (lv + 1)) | (pr & ((1u << lv) - 1));
-            const uint32_t b = a + (1u << lv);
-            const uint64_t w0 = wbase + ((uint64_t)a << d0);
-            const uint32_t j = (uint32_t)(w0 >> (d0 + lv + 1));
-            // 16x16 twiddle matrix rows (c < 2^16: rows 0..15, low 16 bits)
-            const uint32_t e0 = j & 1023, e1 = (j >> 10) & 1023, e2 = (j >> 20) & 1023;
-            const uint32_t c = TWC[e0] ^ TWC[1024 + e1] ^ TWC[2048 + e2];
-            uint32_t row[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                row[k] = TW[e0 * 32 + k] ^ TW[(1024 + e1) * 32 + k] ^ TW[(2048 + e2) * 32 + k];
-            uint32_t *px = lds + (a * 32 + hf * 16) * FT_ROWS + lane;
-            uint32_t *py = lds + (b * 32 + hf * 16) * FT_ROWS + lane;
-            uint32_t x[16], y[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                x[k] = px[k * FT_ROWS];
-                y[k] = py[k * FT_ROWS];
-            }
-            if (INV) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) y[k] ^= x[k];
-            }
-            if (c != 0) {
-                if (c < (1u << 8)) {
-#pragma unroll
-                    for (int blk = 0; blk < 2; blk++) {
-                        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                        for (int jj = 0; jj < 8; jj++)
-#pragma unroll
-                            for (int kk = 0; kk < 8; kk++)
-                                acc[kk] = XAND(acc[kk], y[blk * 8 + jj], 0u - ((row[kk] >> jj) & 1u));
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) x[blk * 8 + kk] ^= acc[kk];
-                    }
-                } else {
-#pragma unroll
-                    for (int k0 = 0; k0 < 16; k0 += 8) {
-                        uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                        for (int jj = 0; jj < 16; jj++)
-#pragma unroll
-                            for (int kk = 0; kk < 8; kk++)
-                                acc[kk] = XAND(acc[kk], y[jj], 0u - ((row[k0 + kk] >> jj) & 1u));
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) x[k0 + kk] ^= acc[kk];
-                    }
-                }
-            }
-            if (!INV) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) y[k] ^= x[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                px[k * FT_ROWS] = x[k];
-                py[k * FT_ROWS] = y[k];
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t s = wave; s < nwt * 32; s += FT2_THREADS / 64) {
-        uint32_t wl = s >> 5, k = s & 31;
-        g[((wbase + ((uint64_t)wl << d0)) * 32 + k) * ROWS] = lds[s * FT_ROWS + lane];
-    }
+    tile_levels<INV>(lds, d, base_w, TW, wave, lane);
+    tile_store(lds, Z, d, base_w, rh, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: the five intra-word levels (4..0 forward, 0..4 inverse), optionally with the pointwise multiply by
-// FFT(a) in between. Level i pairs bit positions p and p + 2^i; the twiddle of position p is
-// point(2*((32w+p) >> (i+1))) = point(w << (5-i)) ^ point(2*(p >> (i+1))): a wave-uniform part and a
-// per-position part that lies in GF(2^8) (compile-time masks QC_MPOS).
+// the five intra-word levels (i = 4..0 forward, 0..4 inverse) on one 32-plane value word W[32]. Level i pairs bit
+// positions p and p + 2^i; the twiddle of position p is point(qw >> i) ^ point(p >> i) with
+// qw = 2^m | (position of the word's bit 0, pruned bits cleared): a wave-uniform part (always a full GF(2^32)
+// element here) and a per-position part in GF(2^8) (compile-time masks QC_MPOS).
 __device__ __forceinline__ uint32_t lowmask(int i) {
     return i == 0 ? 0x55555555u : i == 1 ? 0x33333333u : i == 2 ? 0x0F0F0F0Fu : i == 3 ? 0x00FF00FFu : 0x0000FFFFu;
 }
 
 template <int I, bool INV>
-__device__ __forceinline__ void low_level(uint32_t W0[32], uint32_t W1[32], uint64_t w, const uint32_t *__restrict__ TW,
-                                          const uint32_t *__restrict__ TWC) {
-    const uint32_t A = lowmask(I);
-    constexpr int SH = 1 << I;
-    uint32_t v0[32], v1[32], t0[32], t1[32];
-    if (INV) {  // y ^= x first
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            W0[k] ^= (W0[k] & A) << SH;
-            W1[k] ^= (W1[k] & A) << SH;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        v0[k] = (W0[k] >> SH) & A;
-        v1[k] = (W1[k] >> SH) & A;
-    }
-    // uniform part: block index of the word's first position at this level
-    const uint32_t ju = (uint32_t)(w << (4 - I));
-    twid tw;
-    load_twid(TW, TWC, ju, tw);
-    if (tw.c != 0) {
-        mul_uniform(tw, v0, v1, t0, t1);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 32; k++) t0[k] = t1[k] = 0;
-    }
-    if (I < 4) {  // per-position part, GF(2^8) blocks
-#pragma unroll
-        for (int blk = 0; blk < 4; blk++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                uint32_t a0 = 0, a1 = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t m = d_MPOS[(I * 8 + k) * 8 + j];
-                    a0 = XAND(a0, v0[blk * 8 + j], m);
-                    a1 = XAND(a1, v1[blk * 8 + j], m);
-                }
-                t0[blk * 8 + k] ^= a0;
-                t1[blk * 8 + k] ^= a1;
-            }
-    }
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        W0[k] ^= t0[k];  // t only has bits at the x positions
-        W1[k] ^= t1[k];
-    }
-    if (!INV) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            W0[k] ^= (W0[k] & A) << SH;
-            W1[k] ^= (W1[k] & A) << SH;
-        }
-    }
-}
-
-// MODE 0: forward low levels only (used for FFT(a)); MODE 1: forward, multiply by FFT(a), inverse
-template <int MODE>
-__global__ void __launch_bounds__(256)
-    k_fft_low(uint32_t *__restrict__ D, uint64_t nw, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC,
-              const uint32_t *__restrict__ Amat) {
-    const uint32_t lane = threadIdx.x & 63;
-    uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= nw) return;
-    w = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
-        __builtin_amdgcn_readfirstlane((uint32_t)w);
-    uint32_t *p = D + w * 32 * ROWS + lane;
-    uint32_t W0[32], W1[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        W0[k] = p[k * ROWS];
-        W1[k] = p[k * ROWS + 64];
-    }
-    low_level<4, false>(W0, W1, w, TW, TWC);
-    low_level<3, false>(W0, W1, w, TW, TWC);
-    low_level<2, false>(W0, W1, w, TW, TWC);
-    low_level<1, false>(W0, W1, w, TW, TWC);
-    low_level<0, false>(W0, W1, w, TW, TWC);
-    if (MODE == 1) {
-        const uint32_t *M = Amat + w * 1024;  // wave-uniform address
-        uint32_t t0[32], t1[32];
-#pragma unroll
-        for (int k0 = 0; k0 < 32; k0 += 4) {
-            uint32_t a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const uint32_t m = M[(k0 + kk) * 32 + j];
-                    a0[kk] = XAND(a0[kk], W0[j], m);
-                    a1[kk] = XAND(a1[kk], W1[j], m);
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                t0[k0 + kk] = a0[kk];
-                t1[k0 + kk] = a1[kk];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            W0[k] = t0[k];
-            W1[k] = t1[k];
-        }
-        low_level<0, true>(W0, W1, w, TW, TWC);
-        low_level<1, true>(W0, W1, w, TW, TWC);
-        low_level<2, true>(W0, W1, w, TW, TWC);
-        low_level<3, true>(W0, W1, w, TW, TWC);
-        low_level<4, true>(W0, W1, w, TW, TWC);
-    }
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        p[k * ROWS] = W0[k];
-        p[k * ROWS + 64] = W1[k];
-    }
-}
-
-// ---- single-row variant: one row per lane (half the registers: 4+ waves per SIMD keep both the VALU and the
-// scalar port that extracts the masks busy)
-template <int B, int I>
-__device__ __forceinline__ void low_mul_acc(const twid &tw, const uint32_t v[32], uint32_t W[32]) {
-    constexpr int KB = 8;
-#pragma unroll
-    for (int blk = 0; blk < 32 / B; blk++) {
-#pragma unroll
-        for (int k0 = 0; k0 < B; k0 += KB) {
-            uint32_t a[KB];
-#pragma unroll
-            for (int kk = 0; kk < KB; kk++) a[kk] = 0;
-#pragma unroll
-            for (int j = 0; j < B; j++) {
-#pragma unroll
-                for (int kk = 0; kk < KB; kk++)
-                    a[kk] = XAND(a[kk], v[blk * B + j], 0u - ((tw.row[k0 + kk] >> j) & 1u));
-            }
-#pragma unroll
-            for (int kk = 0; kk < KB; kk++) W[blk * B + k0 + kk] ^= a[kk];
-        }
-    }
-}
-
-template <int I, bool INV>
-__device__ __forceinline__ void low_level1(uint32_t W[32], uint64_t w, const uint32_t *__restrict__ TW,
-                                           const uint32_t *__restrict__ TWC) {
+__device__ __forceinline__ void low_level(uint32_t W[32], uint32_t qw, const uint32_t *__restrict__ TW) {
     const uint32_t A = lowmask(I);
     constexpr int SH = 1 << I;
     uint32_t v[32];
@@ -953,16 +679,19 @@ __device__ __forceinline__ void low_level1(uint32_t W[32], uint64_t w, const uin
     }
 #pragma unroll
     for (int k = 0; k < 32; k++) v[k] = (W[k] >> SH) & A;  // y positions; the updates below touch x positions only
-    const uint32_t ju = (uint32_t)(w << (4 - I));
-    twid tw;
-    load_twid(TW, TWC, ju, tw);
-    if (tw.c != 0) {
-        if (tw.c < (1u << 8))
-            low_mul_acc<8, I>(tw, v, W);
-        else if (tw.c < (1u << 16))
-            low_mul_acc<16, I>(tw, v, W);
-        else
-            low_mul_acc<32, I>(tw, v, W);
+    const uint32_t q = qw >> I;
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += 8) {
+        uint32_t rows[8];
+        tw_rows<8>(TW, q, k0, rows);
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], v[j], 0u - ((rows[kk] >> j) & 1u));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) W[k0 + kk] ^= a[kk];
     }
     if (I < 4) {
 #pragma unroll
@@ -981,131 +710,76 @@ __device__ __forceinline__ void low_level1(uint32_t W[32], uint64_t w, const uin
     }
 }
 
+// K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
+// pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
+// Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
 template <int MODE>
-__global__ void __launch_bounds__(256, 4)
-    k_fft_low1(uint32_t *__restrict__ D, uint64_t nw, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ TWC,
-               const uint32_t *__restrict__ Amat) {
+__global__ void __launch_bounds__(TL_THREADS)
+    k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ Amat) {
+    __shared__ uint32_t lds[512 * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
-    uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (w, row half)
-    if (item >= 2 * nw) return;
-    item = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(item >> 32)) << 32) |
-           __builtin_amdgcn_readfirstlane((uint32_t)item);
-    const uint64_t w = item >> 1;
-    uint32_t *p = D + w * 32 * ROWS + (item & 1) * 64 + lane;
-    uint32_t W[32];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rh = blockIdx.x & 1;
+    const uint32_t o = blockIdx.x >> 1;
+    const uint32_t base_w = tile_base(d, o);
+    tile_load(lds, Z, d, base_w, rh, wave, lane);
+    __syncthreads();
+    tile_levels<false>(lds, d, base_w, TW, wave, lane);
+    const uint32_t nvw = 1u << (d.nb - 5);  // value words in the tile
+    for (uint32_t vi = wave; vi < nvw; vi += TL_WAVES) {
+        uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
+        const uint32_t w = base_w | tile_word(d, vi << 5);
+        const uint32_t qw = (1u << d.m) | ((w & ~d.pmw) << 5);
+        uint32_t W[32];
 #pragma unroll
-    for (int k = 0; k < 32; k++) W[k] = p[k * ROWS];
-    low_level1<4, false>(W, w, TW, TWC);
-    low_level1<3, false>(W, w, TW, TWC);
-    low_level1<2, false>(W, w, TW, TWC);
-    low_level1<1, false>(W, w, TW, TWC);
-    low_level1<0, false>(W, w, TW, TWC);
-    if (MODE == 1) {
-        const uint32_t *M = Amat + w * 1024;  // wave-uniform address
-        uint32_t t[32];
+        for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
+        low_level<4, false>(W, qw, TW);
+        low_level<3, false>(W, qw, TW);
+        low_level<2, false>(W, qw, TW);
+        low_level<1, false>(W, qw, TW);
+        low_level<0, false>(W, qw, TW);
+        if (MODE == 1) {
+            const uint32_t *M = Amat + ((uint64_t)o * nvw + vi) * 1024;  // wave-uniform address
+            uint32_t t[32];
 #pragma unroll
-        for (int k0 = 0; k0 < 32; k0 += 8) {
-            uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k0 = 0; k0 < 32; k0 += 8) {
+                uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
+                for (int j = 0; j < 32; j++) {
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], W[j], M[(k0 + kk) * 32 + j]);
+                    for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], W[j], M[(k0 + kk) * 32 + j]);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) t[k0 + kk] = a[kk];
             }
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) t[k0 + kk] = a[kk];
+            for (int k = 0; k < 32; k++) W[k] = t[k];
+            low_level<0, true>(W, qw, TW);
+            low_level<1, true>(W, qw, TW);
+            low_level<2, true>(W, qw, TW);
+            low_level<3, true>(W, qw, TW);
+            low_level<4, true>(W, qw, TW);
         }
 #pragma unroll
-        for (int k = 0; k < 32; k++) W[k] = t[k];
-        low_level1<0, true>(W, w, TW, TWC);
-        low_level1<1, true>(W, w, TW, TWC);
-        low_level1<2, true>(W, w, TW, TWC);
-        low_level1<3, true>(W, w, TW, TWC);
-        low_level1<4, true>(W, w, TW, TWC);
+        for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
     }
-#pragma unroll
-    for (int k = 0; k < 32; k++) p[k * ROWS] = W[k];
+    __syncthreads();
+    if (MODE == 1) tile_levels<true>(lds, d, base_w, TW, wave, lane);
+    tile_store(lds, Z, d, base_w, rh, wave, lane);
 }
 
-// Amat[w][k][j] bit p = bit k of (FFT(a)[32 w + p] (x) 2^j); FFT(a) is row 0 of Da
-__global__ void k_build_amat(const uint32_t *__restrict__ Da, uint64_t nw, uint32_t *__restrict__ Amat) {
-    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (w, k, j)
-    if (idx >= nw * 1024) return;
-    const uint64_t w = idx >> 10;
+// Amat[(o * nvw + vi)][k][j] bit p = bit k of (FFT(a) value at position p of value word (o, vi)) (x) 2^j; row 0 of Z
+__global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64_t nvals, uint32_t *__restrict__ Amat) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (value word, k, j)
+    if (idx >= nvals * 1024) return;
+    const uint32_t vw = (uint32_t)(idx >> 10);
     const uint32_t k = (idx >> 5) & 31, j = idx & 31;
-    uint32_t m = 0;
-    for (int t = 0; t < 32; t++)
-        if ((d_RTAB[t * 32 + k] >> j) & 1) m ^= Da[(w * 32 + t) * ROWS];
-    Amat[idx] = m;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7: nimber coordinates -> coefficients on 1, g, ..., g^31 (in place), all words
-__global__ void __launch_bounds__(256) k_qc_unpack(uint32_t *__restrict__ D, uint64_t nw) {
-    static constexpr uint32_t GINVROW[32] = {
-#include "qc_ginvrow.inc"
-    };
-    const uint64_t total = nw * ROWS;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t w = idx / ROWS;
-        const uint32_t row = idx % ROWS;
-        uint32_t *p = D + w * 32 * ROWS + row;
-        uint32_t x[32];
-#pragma unroll
-        for (int k = 0; k < 32; k++) x[k] = p[k * ROWS];
-#pragma unroll
-        for (int t = 0; t < 32; t++) {
-            uint32_t y = 0;
-#pragma unroll
-            for (int k = 0; k < 32; k++)
-                if ((GINVROW[t] >> k) & 1) y ^= x[k];
-            p[t * ROWS] = y;
-        }
-    }
-}
-
-// K9: overlap-add of the 31-bit product elements and transpose back to Blocks:
-// T[16*(32w+p) + t] bit row = C_t[w] ^ (C_{16+t}[w] << 1 | C_{16+t}[w-1] >> 31), bit p.
-// One block = 2 consecutive words w; the slabs are staged through LDS (33-word padded groups of 32 rows)
-// so that both the global reads and the Block stores are coalesced.
-#define ST_W 2
-__global__ void __launch_bounds__(128) k_qc_store(const uint32_t *__restrict__ D, uint64_t nw, blk_t *__restrict__ T) {
-    __shared__ uint32_t slab[(ST_W * 128 + 64) * 33];  // [hi planes of w0-1 | w0 | w0+1], group = plane*4 + row/32
-    __shared__ uint32_t tile[ST_W][512 * 4];
-    const uint64_t w0 = (uint64_t)blockIdx.x * ST_W;
-    // stage: groups 0..63 = planes 16..31 of w0-1; groups 64.. = all planes of w0, w0+1
-    for (uint32_t i = threadIdx.x; i < (ST_W * 4096 + 2048) / 4; i += blockDim.x) {
-        uint32_t x = 4 * i;  // word index in the staged range
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (x < 2048) {
-            if (w0 > 0) v = *(const uint4 *)(D + ((w0 - 1) * 32 + 16) * ROWS + x);
-        } else {
-            uint64_t w = w0 + (x - 2048) / 4096;
-            if (w < nw) v = *(const uint4 *)(D + w0 * 32 * ROWS + (x - 2048));
-        }
-        uint32_t g = x >> 5, b = x & 31;
-        uint32_t *d = slab + g * 33 + b;
-        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-    }
-    __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t w = w0 + wave;
-    if (w < nw) {
-        const uint32_t t = lane >> 2, q = lane & 3;
-        uint32_t a[32];
-        const uint32_t *lo = slab + (64 + wave * 128 + t * 4 + q) * 33;
-        const uint32_t *hi = slab + (64 + wave * 128 + (16 + t) * 4 + q) * 33;
-        // previous word's hi planes: for wave 0 the staged w0-1 copy, else the preceding slab
-        const uint32_t *hp = wave == 0 ? slab + (t * 4 + q) * 33 : slab + (64 + (wave - 1) * 128 + (16 + t) * 4 + q) * 33;
-#pragma unroll
-        for (int b = 0; b < 32; b++) a[b] = lo[b] ^ (hi[b] << 1) ^ (hp[b] >> 31);
-        transpose32(a);
-#pragma unroll
-        for (int p = 0; p < 32; p++) tile[wave][(16 * p + t) * 4 + q] = a[p];
-    }
-    __syncthreads();
-    if (w >= nw) return;
-    for (uint32_t i = lane; i < 512; i += 64) T[w * 512 + i] = *(blk_t *)&tile[wave][i * 4];
+    const uint32_t nvw = 1u << (d.nb - 5);
+    const uint32_t w = tile_base(d, vw / nvw) | tile_word(d, (vw % nvw) << 5);
+    uint32_t mm = 0;
+    for (uint32_t t = 0; t < 32; t++)
+        if ((d_RTAB[t * 32 + k] >> j) & 1) mm ^= Z[(uint64_t)(w | tile_word(d, t)) * ROWS];
+    Amat[idx] = mm;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1198,10 +872,11 @@ static inline uint32_t ilog2(uint64_t x) {
     return l;
 }
 
-// runs the conversion on `bufs[cur]`; phases with chunk > 2^16 elements go through the generic ping-pong
-// kernel, the rest through the fused LDS tile kernel (in place). Returns the buffer index holding the result.
-template <int NP>
-static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, uint64_t nwords, bool inverse) {
+// monomial <-> novel basis conversion of the 2^ell_elems low coefficients of every row, on bufs[cur]; phases with
+// chunk > 2^16 go through k_conv_top (fused) or the generic one-phase kernel (ping-pong), the rest through the
+// fused LDS tile kernel (in place). Returns the buffer index holding the result.
+static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse) {
+    const uint64_t nwords = 1ull << (ell_elems - 5);
     std::vector<phase_t> ph;
     conv_rec(ph, ell_elems, 1);
     const uint32_t tb = ell_elems < 16 ? ell_elems : 16;
@@ -1217,12 +892,11 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
             small.n++;
         }
     }
-    const uint64_t total = nwords * NP * ROWS;
+    const uint64_t total = nwords * ROWS;
     const unsigned grid = gridn(total, 256, 1u << 20);
-    const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * NP * 8);
-    const int kid = NP == 16 ? KID_CONV16 : KID_CONV32;
-    const int kid_t = NP == 16 ? KID_CONV16_TILE : KID_CONV32_TILE;
-    // the multi-unit phases fuse into k_conv_top when each is a whole-unit move or a sub-word shift
+    const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * 8);
+    const int kid = inverse ? KID_CONV_INV : KID_CONV_FWD;
+    const int kid_t = inverse ? KID_CONV_INV_TILE : KID_CONV_FWD_TILE;
     conv_phases top;
     top.n = 0;
     bool top_ok = !big.empty() && ell_elems > 16 && ell_elems - 16 <= 7 && !getenv("SOT_NO_TOP");
@@ -1231,34 +905,38 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         uint32_t lpw = ilog2(p.pw);
         if (lpw >= 5 && lpw < 16) top_ok = false;
         if (lpw < 5) shift_sum += 1u << lpw;
-        top.lchunk[top.n] = (uint8_t)ilog2(p.chunk);
-        top.lpw[top.n] = (uint8_t)lpw;
-        top.n++;
+        if (top.n < 48) {
+            top.lchunk[top.n] = (uint8_t)ilog2(p.chunk);
+            top.lpw[top.n] = (uint8_t)lpw;
+            top.n++;
+        } else {
+            top_ok = false;
+        }
     }
     if (shift_sum > 31) top_ok = false;
     const uint32_t lnu = top_ok ? ell_elems - 16 : 0;
     const uint32_t NC = top_ok ? 1024u >> lnu : 0;  // NU * NC * 32 rows = 32768 words
-    const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * NP * 4) : 0;
+    const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * 4) : 0;
     if (!inverse) {
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 0);
+            SOT_LAUNCH(c, kid, k_conv_top<1>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 0);
             cur ^= 1;
         } else {
             for (size_t i = 0; i < big.size(); i++) {
-                SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
+                SOT_LAUNCH(c, kid, k_conv_phase<1>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
                            big[i].chunk, big[i].pw, big[i].half, 0);
                 cur ^= 1;
             }
         }
-        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
+        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
-        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<NP>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
+        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<NP>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 1);
+            SOT_LAUNCH(c, kid, k_conv_top<1>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 1);
             cur ^= 1;
         } else {
             for (size_t i = big.size(); i-- > 0;) {
-                SOT_LAUNCH(c, kid, k_conv_phase<NP>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
+                SOT_LAUNCH(c, kid, k_conv_phase<1>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
                            big[i].chunk, big[i].pw, big[i].half, 1);
                 cur ^= 1;
             }
@@ -1267,27 +945,94 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     return cur;
 }
 
-// forward transform of the 16-plane input in X[xcur] into D0 (levels ell-1 .. 5); low levels left to the caller
-static int forward_to_D(sot_ctx *c, int xcur) {
-    const qc_geom &g = c->g;
-    uint32_t *xb[2] = {c->X0, c->X1};
-    xcur = run_conversion<16>(c, xb, xcur, g.ell - 1, g.nw_in, false);
-    SOT_LAUNCH(c, KID_QC_EXPAND, k_qc_expand, dim3(gridn(g.nw_in * ROWS, 256, 1u << 20)), dim3(256), xb[xcur],
-                       c->D0, g.nw_in);
-    // word-pair levels i = ell-2 .. 5 (d = i - 5), four per pass from the top
-    for (int dtop = (int)g.ell - 7; dtop >= 0;) {
-        int nlev = dtop + 1 < 4 ? dtop + 1 : 4;
-        int d0 = dtop - nlev + 1;
-        if (5 + d0 + 16 >= (int)g.ell)
-            SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile2<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT2_THREADS),
-                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
-        else
-            SOT_LAUNCH(c, KID_FFT_LEVEL, k_fft_tile<false>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS),
-                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
-        dtop = d0 - 1;
+// ---- tile descriptors of the butterfly passes (see fafft_model.py: level r <-> word-index bit m - r - 5)
+static inline bool is_pruned(uint32_t r) { return r == 1 || r == 2 || r == 4 || r == 8 || r == 16; }
+
+static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, const std::vector<uint32_t> &level_r) {
+    // plane_r: pruned levels whose word bit is (or becomes, inside this pass) a plane bit, in plane-bit order;
+    // level_r: levels run by this pass, in forward order (ascending r)
+    tile_desc d;
+    memset(&d, 0, sizeof d);
+    d.m = m;
+    d.zero_bit = 32;
+    auto wb = [&](uint32_t r) { return m - r - 5; };
+    for (uint32_t r : {1u, 2u, 4u, 8u, 16u}) d.pmw |= 1u << wb(r);
+    std::vector<uint32_t> bits_r = plane_r;
+    for (uint32_t r : level_r)
+        if (!is_pruned(r)) bits_r.push_back(r);
+    d.nb = (uint32_t)bits_r.size();
+    for (uint32_t j = 0; j < d.nb; j++) {
+        d.pos[j] = (uint8_t)wb(bits_r[j]);
+        d.tmask |= 1u << d.pos[j];
     }
-    SOT_HIP(hipGetLastError());
-    return SOT_OK;
+    auto tbit_of = [&](uint32_t r) {
+        for (uint32_t j = 0; j < d.nb; j++)
+            if (bits_r[j] == r) return j;
+        return 0u;
+    };
+    d.nlev = 0;
+    for (uint32_t r : level_r) {
+        if (r <= 2) continue;  // tau_lo = 0: these two pruned levels only relabel bits as planes
+        uint32_t np = 0;
+        for (uint32_t p : {1u, 2u, 4u, 8u, 16u})
+            if (p < r) np++;
+        d.lev_r[d.nlev] = (uint8_t)r;
+        d.lev_tbit[d.nlev] = (uint8_t)tbit_of(r);
+        d.lev_np[d.nlev] = (uint8_t)np;
+        d.lev_pruned[d.nlev] = is_pruned(r);
+        d.nlev++;
+    }
+    return d;
+}
+
+struct fft_plan {
+    tile_desc top, mid1, mid2, low;
+    std::vector<tile_desc> w32;  // extra 32-plane word-level passes (m > 25), forward order
+};
+
+static fft_plan make_plan(uint32_t m) {
+    fft_plan p;
+    p.top = make_desc(m, {1, 2, 4, 8}, {1, 2, 3, 4, 5, 6, 7, 8});
+    p.mid1 = make_desc(m, {1, 2, 4, 8}, {9, 10, 11, 12});
+    p.mid2 = make_desc(m, {1, 2, 4, 8, 16}, {13, 14, 15, 16});
+    // 32-plane word levels r = 17 .. m-5; the lowest (up to 4) belong to the fused low kernel
+    const uint32_t last = m - 5;
+    uint32_t nlow = last >= 17 ? last - 16 : 0;
+    uint32_t in_low = nlow < 4 ? nlow : 4;
+    uint32_t r = 17;
+    while (last + 1 - r > in_low) {
+        uint32_t cnt = last + 1 - r - in_low;
+        if (cnt > 4) cnt = 4;
+        std::vector<uint32_t> lv;
+        for (uint32_t k = 0; k < cnt; k++) lv.push_back(r + k);
+        p.w32.push_back(make_desc(m, {1, 2, 4, 8, 16}, lv));
+        r += cnt;
+    }
+    std::vector<uint32_t> lv;
+    for (; r <= last; r++) lv.push_back(r);
+    p.low = make_desc(m, {1, 2, 4, 8, 16}, lv);
+    return p;
+}
+
+static inline unsigned tile_grid(const tile_desc &d) { return (unsigned)((1u << (d.m - 5 - d.nb)) * 2); }
+
+// forward butterflies of an operand (upper half of the row zero) on Z, up to (not including) the low kernel
+static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
+    tile_desc top = p.top;
+    top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
+    SOT_LAUNCH(c, KID_FFT_TOP, (k_tile_fft<false, 8>), dim3(tile_grid(top)), dim3(TL_THREADS), Z, top, c->TW);
+    SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 8>), dim3(tile_grid(p.mid1)), dim3(TL_THREADS), Z, p.mid1, c->TW);
+    SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 8>), dim3(tile_grid(p.mid2)), dim3(TL_THREADS), Z, p.mid2, c->TW);
+    for (auto &d : p.w32)
+        SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 9>), dim3(tile_grid(d)), dim3(TL_THREADS), Z, d, c->TW);
+}
+
+static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
+    for (size_t i = p.w32.size(); i-- > 0;)
+        SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 9>), dim3(tile_grid(p.w32[i])), dim3(TL_THREADS), Z, p.w32[i], c->TW);
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 8>), dim3(tile_grid(p.mid2)), dim3(TL_THREADS), Z, p.mid2, c->TW);
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 8>), dim3(tile_grid(p.mid1)), dim3(TL_THREADS), Z, p.mid1, c->TW);
+    SOT_LAUNCH(c, KID_IFFT_TOP, (k_tile_fft<true, 8>), dim3(tile_grid(p.top)), dim3(TL_THREADS), Z, p.top, c->TW);
 }
 
 static int upload_a_and_transform(sot_ctx *c) {
@@ -1318,14 +1063,18 @@ static int upload_a_and_transform(sot_ctx *c) {
         if ((ap[(g.S + i) >> 5] >> ((g.S + i) & 31)) & 1u) c->a_hi_host[i >> 5] |= 1u << (i & 31);
     SOT_HIP(hipMemcpy(c->a2, ap.data(), ap.size() * 4, hipMemcpyHostToDevice));
     SOT_HIP(hipMemcpy(c->a_hi, c->a_hi_host.data(), c->a_hi_host.size() * 4, hipMemcpyHostToDevice));
-    // FFT(a_lo): row 0 of the plane layout
-    SOT_HIP(hipMemsetAsync(c->X0, 0, g.nw_in * 16 * ROWS * 4, c->stream));
-    hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw_in * 16, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw_in,
-                       c->X0);
-    SOT_TRY(forward_to_D(c, 0));
-    hipLaunchKernelGGL(k_fft_low<0>, dim3(gridn(g.nw, 4)), dim3(256), 0, c->stream, c->D0, g.nw, c->TW, c->TWC,
+    // FFT(a_lo): row 0 of Z
+    const fft_plan plan = make_plan(g.m);
+    SOT_HIP(hipMemsetAsync(c->Z0, 0, g.nw * ROWS * 4, c->stream));
+    SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
+    hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw / 2, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw / 2, c->Z0);
+    uint32_t *zb[2] = {c->Z0, c->Z1};
+    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    fft_forward_upper(c, zb[cur], plan);
+    hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, zb[cur], plan.low, c->TW,
                        (const uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_build_amat, dim3(gridn(g.nw * 1024, 256)), dim3(256), 0, c->stream, c->D0, g.nw, c->Amat);
+    hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * 1024, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
+                       g.nw / 32, c->Amat);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
@@ -1339,38 +1088,35 @@ int qc_init(sot_ctx *c) {
         sot_set_error("unsupported geometry: n_blocks*128 < P");
         return SOT_EINVAL;
     }
-    // FFT capacity S = 8 L bits per operand; up to QC_TAIL_MAX bits above it go through the tail terms
+    // FFT capacity: 2^m product bits, S = 2^(m-1) bits per operand; up to TAIL_MAX operand bits above S go
+    // through the tail terms of k_qc_final. m >= 21 keeps all five pruned levels on word-index bits.
     const uint64_t TAIL_MAX = 256;
-    uint32_t ell = 11;
-    while ((8ull << ell) + TAIL_MAX < cf.P) ell++;
-    g.ell = ell;
-    g.L = 1ull << ell;
-    g.S = 8 * g.L;
-    g.tail = cf.P > g.S ? cf.P - g.S : 0;
-    g.lo_bits = cf.P < g.S ? cf.P : g.S;
-    g.nw_in = g.L / 64;
-    g.nw = g.L / 32;
-    if (ell > 24) {
-        sot_set_error("n too large for the twiddle tables");
+    uint32_t m = 21;
+    while ((1ull << (m - 1)) + TAIL_MAX < cf.P) m++;
+    if (m > 30) {
+        sot_set_error("n too large for the GF(2^32) transform");
         return SOT_EINVAL;
     }
-    SOT_TRY(dev_alloc(c, (void **)&c->X0, g.nw_in * 16 * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->X1, g.nw_in * 16 * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->D0, g.nw * 32 * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->D1, g.nw * 32 * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->Amat, g.nw * 1024 * 4));
+    g.m = m;
+    g.S = 1ull << (m - 1);
+    g.tail = cf.P > g.S ? cf.P - g.S : 0;
+    g.lo_bits = cf.P < g.S ? cf.P : g.S;
+    g.nw = 1ull << (m - 5);
+    SOT_TRY(dev_alloc(c, (void **)&c->Z0, g.nw * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->Z1, g.nw * ROWS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * 1024 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->T, 2 * g.S * 16));
     SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 1024 * 32 * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 1024 * 4));
-    hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 1024 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
+    SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 256 * 32 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 256 * 4));
+    hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 256 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
     SOT_HIP(hipGetLastError());
     return upload_a_and_transform(c);
 }
 
 void qc_free(sot_ctx *c) {
-    void *ptrs[] = {c->X0, c->X1, c->D0, c->D1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }
@@ -1382,36 +1128,61 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     blk_t *V = c->role[role].V;
     const uint64_t nb128 = cf.n_blocks * 128;
     const uint64_t nV = cf.cols * 128;
+    const fft_plan plan = make_plan(g.m);
     if (role == SOT_ROLE_RECEIVER) {
         SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
         SOT_LAUNCH(c, KID_CLEAR_LSB, k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), V, nV);
         SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), V, c->d_points,
                            (uint32_t)npoints, nV);
     }
-    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw_in, 4)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
-                       g.nw_in, c->X0);
-    SOT_TRY(forward_to_D(c, 0));
-    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low1<1>, dim3(gridn(2 * g.nw, 4)), dim3(256), c->D0, g.nw, c->TW, c->TWC,
-                       c->Amat);
-    for (int d0 = 0; d0 <= (int)g.ell - 6;) {
-        int rem = (int)g.ell - 5 - d0;
-        int nlev = rem < 4 ? rem : 4;
-        if (5 + d0 + 16 >= (int)g.ell)
-            SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile2<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT2_THREADS),
-                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
-        else
-            SOT_LAUNCH(c, KID_IFFT_LEVEL, k_fft_tile<true>, dim3((unsigned)((g.nw >> nlev) * 2)), dim3(FT_THREADS),
-                       c->D0, (uint32_t)d0, (uint32_t)nlev, c->TW, c->TWC);
-        d0 += nlev;
-    }
-    SOT_LAUNCH(c, KID_QC_UNPACK, k_qc_unpack, dim3(gridn(g.nw * ROWS, 256, 1u << 20)), dim3(256), c->D0, g.nw);
-    uint32_t *db[2] = {c->D0, c->D1};
-    int cur = run_conversion<32>(c, db, 0, g.ell, g.nw, true);
-    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, ST_W)), dim3(64 * ST_W), db[cur], g.nw, c->T);
+    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
+               g.nw / 2, c->Z0);
+    uint32_t *zb[2] = {c->Z0, c->Z1};
+    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    fft_forward_upper(c, zb[cur], plan);
+    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), zb[cur], plan.low, c->TW,
+               c->Amat);
+    fft_inverse_upper(c, zb[cur], plan);
+    cur = run_conversion(c, zb, cur, g.m, true);
+    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, LD_W)), dim3(256), zb[cur], g.nw, c->T);
     SOT_LAUNCH(c, KID_QC_FINAL, k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), V, nb128, cf.P, g.S, g.tail,
                        cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[role].encoded = true;
+    return SOT_OK;
+}
+
+// ---- debug / validation hook: runs the stages of the transform on ONE row supplied by the host (row 0 of Z; the
+// other rows are zero) so that tests can compare every stage with fafft_model.py.
+//   stage 0: forward basis conversion of the low half     stage 1: + top pass (levels 1..8)
+//   stage 2: + levels 9..12   stage 3: + levels 13..16 (and the extra 32-plane passes)   stage 4: + low levels (full
+//   forward transform)
+int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out) {
+    const qc_geom &g = c->g;
+    SOT_HIP(hipSetDevice(c->device));
+    const fft_plan plan = make_plan(g.m);
+    SOT_HIP(hipMemsetAsync(c->Z0, 0, g.nw * ROWS * 4, c->stream));
+    SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
+    SOT_HIP(hipMemcpy2DAsync(c->Z0, ROWS * 4, row_in, 4, 4, g.nw / 2, hipMemcpyHostToDevice, c->stream));
+    uint32_t *zb[2] = {c->Z0, c->Z1};
+    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    uint32_t *Z = zb[cur];
+    tile_desc top = plan.top;
+    top.zero_bit = 0;
+    if (stage >= 1) hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(top)), dim3(TL_THREADS), 0, c->stream, Z, top, c->TW);
+    if (stage >= 2)
+        hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(plan.mid1)), dim3(TL_THREADS), 0, c->stream, Z, plan.mid1, c->TW);
+    if (stage >= 3) {
+        hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(plan.mid2)), dim3(TL_THREADS), 0, c->stream, Z, plan.mid2, c->TW);
+        for (auto &d : plan.w32)
+            hipLaunchKernelGGL((k_tile_fft<false, 9>), dim3(tile_grid(d)), dim3(TL_THREADS), 0, c->stream, Z, d, c->TW);
+    }
+    if (stage >= 4)
+        hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, Z, plan.low, c->TW,
+                           (const uint32_t *)nullptr);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpy2DAsync(row_out, 4, Z, ROWS * 4, 4, g.nw, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }

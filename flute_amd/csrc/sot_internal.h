@@ -33,15 +33,13 @@ struct aes_rk {
 };
 void aes_expand_key_host(const uint8_t key[16], aes_rk *out);
 
-// geometry of the GF(2^32) additive-FFT product used by the QC encode
+// geometry of the GF(2^32) Frobenius additive-FFT product used by the QC encode (qc.hip)
 struct qc_geom {
-    uint32_t ell;      // log2 L, L = number of evaluation points
-    uint64_t L;        // points; each operand holds at most L/2 elements of 16 bits
-    uint64_t S;        // bits per operand handled by the FFT = 8 L
+    uint32_t m;        // log2 of the product capacity in bits (>= 21)
+    uint64_t S;        // bits per operand handled by the FFT = 2^(m-1)
     uint64_t tail;     // P - S if P > S else 0 (handled by the schoolbook tail terms)
     uint64_t lo_bits;  // min(P, S)
-    uint64_t nw_in;    // words per plane of the 16-plane input  = L / 64
-    uint64_t nw;       // words per plane of the 32-plane domain = L / 32
+    uint64_t nw;       // 32-bit words per bit row = 2^(m-5)
 };
 
 // kernel ids for the optional per-kernel HIP-event timing (sot_prof_*)
@@ -59,17 +57,17 @@ enum sot_kid {
     KID_MT_BITS,
     KID_CLEAR_LSB,
     KID_QC_LOAD,
-    KID_CONV16,
-    KID_QC_EXPAND,
-    KID_FFT_LEVEL,
+    KID_CONV_FWD,
+    KID_CONV_FWD_TILE,
+    KID_FFT_TOP,
+    KID_FFT_MID,
     KID_FFT_LOW_MUL,
-    KID_IFFT_LEVEL,
-    KID_QC_UNPACK,
-    KID_CONV32,
+    KID_IFFT_MID,
+    KID_IFFT_TOP,
+    KID_CONV_INV_TILE,
+    KID_CONV_INV,
     KID_QC_STORE,
     KID_QC_FINAL,
-    KID_CONV16_TILE,
-    KID_CONV32_TILE,
     KID_COUNT
 };
 extern const char *const SOT_KID_NAMES[KID_COUNT];
@@ -103,10 +101,9 @@ struct sot_ctx {
     uint32_t *d_rks = nullptr;  // root PRG round keys, [T][44]
     uint64_t rks_cap = 0;
     // QC scratch
-    uint32_t *X0 = nullptr, *X1 = nullptr;  // 16-plane input domain, ping-pong
-    uint32_t *D0 = nullptr, *D1 = nullptr;  // 32-plane FFT domain, ping-pong
+    uint32_t *Z0 = nullptr, *Z1 = nullptr;  // bit rows [word][128 rows], ping-pong (the transform runs in place)
     uint32_t *TW = nullptr, *TWC = nullptr; // twiddle matrix tables
-    uint32_t *Amat = nullptr;               // per-word multiply-by-FFT(a) bit matrices [nw][32][32]
+    uint32_t *Amat = nullptr;               // per value word multiply-by-FFT(a) bit matrices [nw/32][32][32]
     blk_t *T = nullptr;                     // product a_lo * b_lo in Block form, 2 S Blocks
     uint32_t *a2 = nullptr;                 // a mod (x^P - 1), bit vector repeated twice (words)
     uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
@@ -152,5 +149,6 @@ int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk
 int qc_init(sot_ctx *c);
 void qc_free(sot_ctx *c);
 int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints);
+int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out);
 
 int dev_alloc(sot_ctx *c, void **p, uint64_t bytes);

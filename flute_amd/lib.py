@@ -28,6 +28,7 @@ EXPORTS = [
     "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_random_silent_send",
     "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
+    "sot_qc_transform_row", "sot_qc_log2_capacity",
 ]
 
 
@@ -77,6 +78,9 @@ def load_library():
     L.sot_aes128_encrypt.argtypes = [i32, P, P, P, u64]
     L.sot_cr_hash.argtypes = [i32, P, P, u64]
     L.sot_qc_dual_encode_host.argtypes = [P, i32, P, P, u64, P]
+    L.sot_qc_transform_row.argtypes = [P, P, i32, P]
+    L.sot_qc_log2_capacity.argtypes = [P]
+    L.sot_qc_log2_capacity.restype = C.c_uint32
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or name.startswith("sot_") and fn.restype == C.c_int:

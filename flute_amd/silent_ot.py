@@ -126,6 +126,18 @@ class Engine:
     def sync(self):
         check(self.lib.sot_ctx_sync(self.h))
 
+    # ---- validation hook of the GF(2)[x] product (sot_qc_transform_row)
+    def qc_log2_capacity(self):
+        return int(self.lib.sot_qc_log2_capacity(self.h))
+
+    def qc_transform_row(self, row_words, stage):
+        m = self.qc_log2_capacity()
+        row = np.ascontiguousarray(row_words, dtype=np.uint32)
+        assert row.size == 1 << (m - 6)
+        out = np.zeros(1 << (m - 5), dtype=np.uint32)
+        check(self.lib.sot_qc_transform_row(self.h, _p(row), stage, _p(out)))
+        return out
+
     # ---- per-kernel HIP-event timing (sot_prof_*)
     def prof_enable(self, on=True):
         check(self.lib.sot_prof_enable(self.h, 1 if on else 0))

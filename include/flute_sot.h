@@ -145,6 +145,14 @@ int sot_cr_hash(int device, const void *in, void *out, uint64_t nblocks);
  * runs the same encode kernels; result (n Blocks) is written to blocks_out and kept in HBM for the hashes. */
 int sot_qc_dual_encode_host(sot_ctx *ctx, int role, const void *rT, const uint64_t *points, uint64_t npoints,
                             void *blocks_out);
+/* Validation hook for the product inside sot_qc_encode (no reference counterpart: bitpolymul's transform,
+ * bitpolymul2/bitpolymul.c:168-279, is replaced by a Frobenius-pruned additive FFT over GF(2^32)).
+ * Runs the forward transform stages on ONE bit row given by the host (2^(m-6) words = the low half of the
+ * 2^m-bit capacity, m = sot_qc_log2_capacity) and returns the 2^(m-5) words of that row after
+ * stage 0: basis conversion, 1: + levels 1..8, 2: + levels 9..12, 3: + levels 13..m-9, 4: all levels.
+ * tests compare the result with the executable model flute_amd/csrc/fafft_model.py. */
+int sot_qc_transform_row(sot_ctx *ctx, const uint32_t *row_in, int stage, uint32_t *row_out);
+uint32_t sot_qc_log2_capacity(const sot_ctx *ctx);
 
 #ifdef __cplusplus
 }
