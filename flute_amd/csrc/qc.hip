@@ -354,119 +354,116 @@ __global__ void __launch_bounds__(CT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2c: all conversion phases whose chunk spans several 2^16-element units, fused in LDS, in place.
-// Tile = every unit u (NU = 2^(ell-16)) x NC columns x 32 rows of one plane; column 0 is a halo: the word that
-// linearly precedes column 1 (offset o0 - 1, or offset 2047 of the same unit when o0 == 0, "wrap"). Two kinds of
-// phases occur here (gf2fft_model.conversion_phases): pw >= 2^16 (whole units move: plain word XORs between
-// units) and pw < 32 (a sub-word shift along the linear element index). The five sub-word phases shift by at
-// most 31 bits in total, so one halo word per unit supplies every bit that crosses into the tile; its low bits
-// decay phase by phase and it is never written back.
-#define TOPK_ROWS 32
-#define TOPK_RQ 8  // row quads
-__device__ __forceinline__ void top_fold(u4 *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
-                                         uint32_t lpw) {
-    const uint32_t lcr = 31 - __clz(NC * TOPK_RQ);  // NC and TOPK_ROWS are powers of two
-    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1, nchunks = NU >> (lchunk - 16);
-    if (lpw >= 16) {
-        const uint32_t pw_u = 1u << (lpw - 16);
-        const uint32_t items = nchunks * pw_u * NC * TOPK_RQ;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t cr = it & ((1u << lcr) - 1), uj = it >> lcr;
-            uint32_t c = uj >> (lpw - 16), j = uj & (pw_u - 1);
-            uint32_t ud = c * chunk_u + half_u + j, us = ud + half_u - pw_u;
-            lds[ud * NC * TOPK_RQ + cr] ^= lds[us * NC * TOPK_RQ + cr];
-        }
-    } else if (wrap) {
-        const uint32_t pw = 1u << lpw;
-        const uint32_t items = nchunks * TOPK_RQ;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it % TOPK_RQ, c = it / TOPK_RQ;
-            uint32_t ud = c * chunk_u + half_u, us = c * chunk_u + chunk_u - 1;
-            lds[(ud * NC + 1) * TOPK_RQ + r] ^= lds[(us * NC + 0) * TOPK_RQ + r] >> (32 - pw);
-        }
+// K2c: the Taylor-expansion phases at y = x^(2^16) + x whose chunk spans several units but whose shift pw is
+// smaller than a unit (gf2fft_model.conversion_phases: chunk = 2^(pb+17), pw = 2^pb), fused in LDS, out of place.
+// Tile = the NU units of one independent group x NC columns (words at the same offsets of every unit) x 4 RQ rows.
+// The first HW columns are a halo: the words that linearly precede the payload columns (offsets o0-HW .. o0-1, or,
+// for the tile at o0 = 0 ("wrap"), the LAST HW words of each unit, which precede offset 0 of the next unit).
+// Every phase only pulls data from lower linear offsets (shift: lo[e] ^= H[e - pw]) or from the end of a unit
+// into the start of one (fold: H[j] ^= H[j + half - pw], j < pw), so with HW >= the sum of the shifts the payload
+// is exact; the halo decays from its low end and is never written back.
+//   group A: unit 2^21 bits, pw = 2^5 .. 2^(R-1) bits (whole words)      group B: unit 2^16 bits, pw = 1 .. 16 bits
+struct taylor_desc {
+    uint32_t lus;  // log2(unit bits)
+    uint32_t lnu;  // log2(units per group)
+    uint32_t lnc;  // log2(columns per tile, halo included)
+    uint32_t hw;   // halo columns
+    uint32_t lrq;  // log2(row quads per tile)
+    uint32_t nph;
+    uint8_t lchunk[8], lpw[8];
+};
+
+__device__ __forceinline__ u4 ty_fetch(const u4 *lds, const taylor_desc &t, bool wrap, uint32_t us, uint32_t d,
+                                       uint32_t col, int32_t cs, uint32_t r) {
+    const u4 zero = {0, 0, 0, 0};
+    if (cs < 0) return zero;
+    if (wrap && col >= t.hw && (uint32_t)cs < t.hw) {  // crossed offset 0: end of the preceding unit of H
+        if (d == 0) return zero;
+        us -= 1;
+    }
+    return lds[(((us << t.lnc) + (uint32_t)cs) << t.lrq) + r];
+}
+
+__device__ __forceinline__ void ty_shift(u4 *lds, const taylor_desc &t, bool wrap, uint32_t lchunk, uint32_t lpw) {
+    const uint32_t lhalf = lchunk - 1 - t.lus;  // log2(units per half chunk)
+    const uint32_t half_u = 1u << lhalf;
+    const uint32_t sw = (1u << lpw) >> 5, sb = (1u << lpw) & 31u;
+    const uint32_t items = 1u << (t.lnu - 1 + t.lnc + t.lrq);
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        const uint32_t r = it & ((1u << t.lrq) - 1u);
+        const uint32_t col = (it >> t.lrq) & ((1u << t.lnc) - 1u);
+        const uint32_t ui = it >> (t.lrq + t.lnc);
+        const uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
+        const uint32_t ud = (c << (lhalf + 1)) + d, us = ud + half_u;
+        u4 h = ty_fetch(lds, t, wrap, us, d, col, (int32_t)col - (int32_t)sw, r);
+        if (sb) h = (h << sb) | (ty_fetch(lds, t, wrap, us, d, col, (int32_t)col - (int32_t)sw - 1, r) >> (32 - sb));
+        lds[(((ud << t.lnc) + col) << t.lrq) + r] ^= h;
     }
 }
 
-__device__ __forceinline__ void top_shift(u4 *lds, uint32_t NU, uint32_t NC, bool wrap, uint32_t lchunk,
-                                          uint32_t lpw) {
-    const uint32_t lcr = 31 - __clz(NC * TOPK_RQ);
-    const uint32_t lhalf = lchunk - 17;
-    const uint32_t chunk_u = 1u << (lchunk - 16), half_u = chunk_u >> 1;
-    const uint32_t items = (NU / 2) * NC * TOPK_RQ;
-    if (lpw >= 16) {
-        const uint32_t pw_u = 1u << (lpw - 16);
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t cr = it & ((1u << lcr) - 1), ui = it >> lcr;
-            uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
-            if (d >= pw_u) {
-                uint32_t ud = c * chunk_u + d, us = c * chunk_u + half_u + d - pw_u;
-                lds[ud * NC * TOPK_RQ + cr] ^= lds[us * NC * TOPK_RQ + cr];
-            }
-        }
-    } else {
-        const uint32_t pw = 1u << lpw;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), ui = it >> lcr;
-            uint32_t c = ui >> lhalf, d = ui & (half_u - 1);
-            uint32_t ud = c * chunk_u + d, us = ud + half_u;
-            u4 h = lds[(us * NC + col) * TOPK_RQ + r] << pw;
-            if (col >= 2) {
-                h |= lds[(us * NC + col - 1) * TOPK_RQ + r] >> (32 - pw);
-            } else if (col == 1) {
-                if (!wrap)
-                    h |= lds[(us * NC + 0) * TOPK_RQ + r] >> (32 - pw);
-                else if (d != 0)  // offset 0: the preceding word is offset 2047 of the previous unit
-                    h |= lds[((us - 1) * NC + 0) * TOPK_RQ + r] >> (32 - pw);
-            }
-            lds[(ud * NC + col) * TOPK_RQ + r] ^= h;
-        }
+__device__ __forceinline__ void ty_fold(u4 *lds, const taylor_desc &t, bool wrap, uint32_t lchunk, uint32_t lpw) {
+    if (!wrap) return;
+    const uint32_t lhalf = lchunk - 1 - t.lus;
+    const uint32_t half_u = 1u << lhalf;
+    const uint32_t nchunks = 1u << (t.lnu - lhalf - 1);
+    const uint32_t sw = (1u << lpw) >> 5, sb = (1u << lpw) & 31u;
+    const uint32_t nx = sb ? 1u : sw;
+    const uint32_t items = (nchunks * nx) << t.lrq;
+    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+        const uint32_t r = it & ((1u << t.lrq) - 1u);
+        const uint32_t x = (it >> t.lrq) % nx, c = (it >> t.lrq) / nx;
+        const uint32_t uh0 = (c << (lhalf + 1)) + half_u, uhl = uh0 + half_u - 1;
+        u4 v = lds[(((uhl << t.lnc) + t.hw - nx + x) << t.lrq) + r];
+        if (sb) v = v >> (32 - sb);
+        lds[(((uh0 << t.lnc) + t.hw + x) << t.lrq) + r] ^= v;
     }
 }
 
-template <int NP>
 __global__ void __launch_bounds__(CT_THREADS)
-    k_conv_top(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, uint32_t lnu, uint32_t lnc,
-               conv_phases ph, int inverse) {
-    __shared__ u4 lds[8192 + 256];
-    const uint32_t NU = 1u << lnu, NC = 1u << lnc;
-    const uint32_t W = NC - 1;  // payload columns
-    // blockIdx.x = ((colblock * NP) + plane) * 4 + rowgrp
-    const uint32_t rowgrp = blockIdx.x & 3;
-    const uint32_t plane = (blockIdx.x >> 2) % NP;
-    const uint32_t cb = (blockIdx.x >> 2) / NP;
+    k_conv_taylor(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, taylor_desc t, uint32_t ncoltiles,
+                  int inverse) {
+    __shared__ u4 lds[8192];
+    const uint32_t UW = 1u << (t.lus - 5);  // words per unit
+    const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
+    const uint32_t nrg = 32u >> t.lrq;  // row groups
+    const uint32_t rg = blockIdx.x % nrg;
+    const uint32_t cb = (blockIdx.x / nrg) % ncoltiles;
+    const uint32_t grp = (blockIdx.x / nrg) / ncoltiles;
     const uint32_t o0 = cb * W;
     const bool wrap = o0 == 0;
-    // out of place: neighbouring tiles read each other's edge words as halos
-    const uint32_t *g = Din + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
-    uint32_t *go = Dout + (uint64_t)plane * ROWS + rowgrp * TOPK_ROWS;
-    const uint32_t items = NU * NC * TOPK_RQ;
+    const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
+    const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), u = it >> (lnc + 3);
-        uint32_t o = col ? o0 + col - 1 : (wrap ? 2047u : o0 - 1);
+        const uint32_t r = it & ((1u << t.lrq) - 1u);
+        const uint32_t col = (it >> t.lrq) & (NC - 1);
+        const uint32_t u = it >> (t.lrq + t.lnc);
+        const uint32_t o = col >= t.hw ? o0 + col - t.hw : (wrap ? UW - t.hw + col : o0 - t.hw + col);
         u4 v = {0, 0, 0, 0};
-        if (o < 2048) v = *(const u4 *)(g + ((uint64_t)u * 2048 + o) * NP * ROWS + 4 * r);
+        if (o < UW) v = *(const u4 *)(Din + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r);
         lds[it] = v;
     }
     __syncthreads();
-    for (int q = 0; q < ph.n; q++) {
-        const int i = inverse ? ph.n - 1 - q : q;
-        const uint32_t lchunk = ph.lchunk[i], lpw = ph.lpw[i];
+    for (uint32_t q = 0; q < t.nph; q++) {
+        const uint32_t i = inverse ? t.nph - 1 - q : q;
+        const uint32_t lchunk = t.lchunk[i], lpw = t.lpw[i];
         if (!inverse) {
-            top_fold(lds, NU, NC, wrap, lchunk, lpw);
+            ty_fold(lds, t, wrap, lchunk, lpw);
             __syncthreads();
-            top_shift(lds, NU, NC, wrap, lchunk, lpw);
+            ty_shift(lds, t, wrap, lchunk, lpw);
         } else {
-            top_shift(lds, NU, NC, wrap, lchunk, lpw);
+            ty_shift(lds, t, wrap, lchunk, lpw);
             __syncthreads();
-            top_fold(lds, NU, NC, wrap, lchunk, lpw);
+            ty_fold(lds, t, wrap, lchunk, lpw);
         }
         __syncthreads();
     }
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        uint32_t r = it % TOPK_RQ, col = (it / TOPK_RQ) & (NC - 1), u = it >> (lnc + 3);
-        if (col == 0) continue;
-        uint32_t o = o0 + col - 1;
-        if (o < 2048) *(u4 *)(go + ((uint64_t)u * 2048 + o) * NP * ROWS + 4 * r) = lds[it];
+        const uint32_t r = it & ((1u << t.lrq) - 1u);
+        const uint32_t col = (it >> t.lrq) & (NC - 1);
+        const uint32_t u = it >> (t.lrq + t.lnc);
+        if (col < t.hw) continue;
+        const uint32_t o = o0 + col - t.hw;
+        if (o < UW) *(u4 *)(Dout + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r) = lds[it];
     }
 }
 
@@ -493,10 +490,12 @@ __global__ void k_build_tw(uint32_t *__restrict__ TW, uint32_t *__restrict__ TWC
 // rows k0 .. k0+N-1 of the matrix of point(q); q and k0 are wave-uniform: everything stays in SGPRs
 template <int N>
 __device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_t q, uint32_t k0, uint32_t rows[N]) {
-    const uint32_t *t0 = TW + ((q & 255) << 5) + k0;
-    const uint32_t *t1 = TW + ((256 + ((q >> 8) & 255)) << 5) + k0;
-    const uint32_t *t2 = TW + ((512 + ((q >> 16) & 255)) << 5) + k0;
-    const uint32_t *t3 = TW + ((768 + (q >> 24)) << 5) + k0;
+    constexpr int AL = N >= 8 ? 32 : 4 * N;  // k0 is a multiple of N: lets the loads merge into s_load_dwordx8
+    const uint32_t *tb = (const uint32_t *)__builtin_assume_aligned(TW, 128);
+    const uint32_t *t0 = (const uint32_t *)__builtin_assume_aligned(tb + ((q & 255) << 5) + k0, AL);
+    const uint32_t *t1 = (const uint32_t *)__builtin_assume_aligned(tb + ((256 + ((q >> 8) & 255)) << 5) + k0, AL);
+    const uint32_t *t2 = (const uint32_t *)__builtin_assume_aligned(tb + ((512 + ((q >> 16) & 255)) << 5) + k0, AL);
+    const uint32_t *t3 = (const uint32_t *)__builtin_assume_aligned(tb + ((768 + (q >> 24)) << 5) + k0, AL);
 #pragma unroll
     for (int k = 0; k < N; k++) rows[k] = t0[k] ^ t1[k] ^ t2[k] ^ t3[k];
 }
@@ -508,13 +507,13 @@ __device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_
 // planes of a value are K consecutive LDS slots.
 struct tile_desc {
     uint32_t m;      // log2 capacity
-    uint32_t nb;     // tile bits
+    uint32_t nb;     // tile bits (<= 9)
     uint32_t tmask;  // word-index bits that belong to the tile
     uint32_t pmw;    // word-index bits of the pruned levels
     uint32_t zero_bit;  // tile bit whose "1" half is known to be zero on input (forward transform of an operand); 32 = none
     uint32_t nlev;
-    uint8_t pos[12];
-    uint8_t lev_r[8], lev_tbit[8], lev_np[8], lev_pruned[8];
+    uint64_t posq;    // 5 bits per tile bit: its word-index bit (packed so that the kernels never index kernarg memory)
+    uint32_t lev[8];  // r | tbit << 8 | np << 16 | pruned << 24
 };
 
 __device__ __forceinline__ uint32_t tile_base(const tile_desc &d, uint32_t o) {
@@ -528,7 +527,8 @@ __device__ __forceinline__ uint32_t tile_base(const tile_desc &d, uint32_t o) {
 }
 __device__ __forceinline__ uint32_t tile_word(const tile_desc &d, uint32_t t) {
     uint32_t w = 0;
-    for (uint32_t j = 0; j < d.nb; j++) w |= ((t >> j) & 1u) << d.pos[j];
+#pragma unroll
+    for (int j = 0; j < 9; j++) w |= ((t >> j) & 1u) << ((uint32_t)(d.posq >> (5 * j)) & 31u);
     return w;
 }
 
@@ -536,21 +536,38 @@ __device__ __forceinline__ uint32_t tile_word(const tile_desc &d, uint32_t t) {
 #define TL_THREADS 1024
 #define TL_WAVES (TL_THREADS / 64)
 
+// all loads of a wave are issued before the first LDS store (2^NB / 16 granules in flight per wave)
+template <int NB>
 __device__ __forceinline__ void tile_load(uint32_t *lds, const uint32_t *__restrict__ Z, const tile_desc &d,
                                           uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
+    constexpr int PER = (1 << NB) / TL_WAVES;
     const uint32_t nslots = 1u << d.nb;
-    for (uint32_t s = wave; s < nslots; s += TL_WAVES) {
-        uint32_t v = 0;
-        if (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u))
-            v = Z[(uint64_t)(base_w | tile_word(d, s)) * ROWS + rh * TL_ROWS + lane];
-        lds[s * TL_ROWS + lane] = v;
+    const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+    uint32_t v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t s = wave + TL_WAVES * i;
+        v[i] = 0;
+        if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u)))
+            v[i] = g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t s = wave + TL_WAVES * i;
+        if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
     }
 }
+template <int NB>
 __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__restrict__ Z, const tile_desc &d,
                                            uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
+    constexpr int PER = (1 << NB) / TL_WAVES;
     const uint32_t nslots = 1u << d.nb;
-    for (uint32_t s = wave; s < nslots; s += TL_WAVES)
-        Z[(uint64_t)(base_w | tile_word(d, s)) * ROWS + rh * TL_ROWS + lane] = lds[s * TL_ROWS + lane];
+    uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t s = wave + TL_WAVES * i;
+        if (s < nslots) g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS] = lds[s * TL_ROWS + lane];
+    }
 }
 
 // one work item of a butterfly level: outputs c0 .. c0+NO-1 (NO = min(K, 8)) of the butterfly whose x planes sit in
@@ -578,6 +595,7 @@ __device__ __forceinline__ void bfly_item(const uint32_t *lds, uint32_t xs, uint
     for (int j = 0; j < K; j++) {
 #pragma unroll
         for (int kk = 0; kk < NO; kk++) acc[kk] = XAND(acc[kk], y[j], 0u - ((rows[kk] >> j) & 1u));
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int kk = 0; kk < NO; kk++) xn[kk] = acc[kk];
@@ -599,8 +617,9 @@ __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, u
                                             const uint32_t *__restrict__ TW, uint32_t wave, uint32_t lane) {
     for (uint32_t qi = 0; qi < d.nlev; qi++) {
         const uint32_t L = INV ? d.nlev - 1 - qi : qi;
-        const uint32_t r = d.lev_r[L], tbit = d.lev_tbit[L], np = d.lev_np[L];
-        const bool pruned = d.lev_pruned[L] != 0;
+        const uint32_t lv = d.lev[L];
+        const uint32_t r = lv & 255u, tbit = (lv >> 8) & 255u, np = (lv >> 16) & 255u;
+        const bool pruned = (lv >> 24) != 0;
         const uint32_t K = 1u << np;
         const uint32_t lnch = K > 8 ? np - 3 : 0;  // log2(output chunks per butterfly)
         const uint32_t nitems = (1u << (d.nb - 1 - np)) << lnch;
@@ -644,19 +663,48 @@ __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, u
     }
 }
 
-// word-level butterfly passes (top / mid levels): gather, levels, scatter
+// whole-unit phases of the basis conversion (unit = 2^16 coefficients = 2048 words; pw and half are multiples of
+// a unit): plain XORs between granules with the same offset in different units. They commute with the phases
+// that are local to a unit, so they run in the same LDS tile as the top butterfly levels (whose word bits are
+// unit-index bits). The host flattens them into a list of (dst slot, src slot) moves grouped in hazard-free steps
+// (fold / shift of each phase); a 16-lane group moves one granule (64 rows x 4 B) per list entry.
+#define UP_MAX_STEPS 64
+struct unit_phases {
+    uint32_t nsteps;
+    uint32_t step_end[UP_MAX_STEPS];  // list index one past the last move of step s
+    const uint32_t *list;             // device memory: dst | src << 16
+};
+
+__device__ __forceinline__ void tile_unit_phases(uint32_t *lds, const unit_phases &up) {
+    u4 *l4 = (u4 *)lds;
+    const uint32_t rq = threadIdx.x & 15, g = threadIdx.x >> 4;
+    uint32_t start = 0;
+    for (uint32_t st = 0; st < up.nsteps; st++) {
+        const uint32_t end = up.step_end[st];
+        for (uint32_t it = start + g; it < end; it += TL_THREADS / 16) {
+            const uint32_t pr = up.list[it];
+            l4[(pr & 0xffffu) * 16 + rq] ^= l4[(pr >> 16) * 16 + rq];
+        }
+        start = end;
+        __syncthreads();
+    }
+}
+
+// word-level butterfly passes (top / mid levels): gather, [unit phases,] levels, scatter
 template <bool INV, int NB>
 __global__ void __launch_bounds__(TL_THREADS)
-    k_tile_fft(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW) {
+    k_tile_fft(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, unit_phases up) {
     __shared__ uint32_t lds[(1 << NB) * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t rh = blockIdx.x & 1;
     const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
-    tile_load(lds, Z, d, base_w, rh, wave, lane);
+    tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
+    if (!INV && up.nsteps) tile_unit_phases(lds, up);
     tile_levels<INV>(lds, d, base_w, TW, wave, lane);
-    tile_store(lds, Z, d, base_w, rh, wave, lane);
+    if (INV && up.nsteps) tile_unit_phases(lds, up);
+    tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -689,6 +737,7 @@ __device__ __forceinline__ void low_level(uint32_t W[32], uint32_t qw, const uin
         for (int j = 0; j < 32; j++) {
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], v[j], 0u - ((rows[kk] >> j) & 1u));
+            __builtin_amdgcn_sched_barrier(0);  // keep the scalar mask extraction next to its use (SGPR pressure)
         }
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) W[k0 + kk] ^= a[kk];
@@ -722,7 +771,7 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t rh = blockIdx.x & 1;
     const uint32_t o = blockIdx.x >> 1;
     const uint32_t base_w = tile_base(d, o);
-    tile_load(lds, Z, d, base_w, rh, wave, lane);
+    tile_load<9>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
     tile_levels<false>(lds, d, base_w, TW, wave, lane);
     const uint32_t nvw = 1u << (d.nb - 5);  // value words in the tile
@@ -739,18 +788,16 @@ __global__ void __launch_bounds__(TL_THREADS)
         low_level<1, false>(W, qw, TW);
         low_level<0, false>(W, qw, TW);
         if (MODE == 1) {
-            const uint32_t *M = Amat + ((uint64_t)o * nvw + vi) * 1024;  // wave-uniform address
+            // Amat[value word][j][k]: for every input plane j the 32 output masks are contiguous (2 x s_load_dwordx16)
+            const uint32_t *M = (const uint32_t *)__builtin_assume_aligned(Amat + ((uint64_t)o * nvw + vi) * 1024, 128);
             uint32_t t[32];
 #pragma unroll
-            for (int k0 = 0; k0 < 32; k0 += 8) {
-                uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < 32; k++) t[k] = 0;
 #pragma unroll
-                for (int j = 0; j < 32; j++) {
+            for (int j = 0; j < 32; j++) {
 #pragma unroll
-                    for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], W[j], M[(k0 + kk) * 32 + j]);
-                }
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) t[k0 + kk] = a[kk];
+                for (int k = 0; k < 32; k++) t[k] = XAND(t[k], W[j], M[j * 32 + k]);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);  // bounds the SGPRs holding masks to two rows
             }
 #pragma unroll
             for (int k = 0; k < 32; k++) W[k] = t[k];
@@ -765,15 +812,15 @@ __global__ void __launch_bounds__(TL_THREADS)
     }
     __syncthreads();
     if (MODE == 1) tile_levels<true>(lds, d, base_w, TW, wave, lane);
-    tile_store(lds, Z, d, base_w, rh, wave, lane);
+    tile_store<9>(lds, Z, d, base_w, rh, wave, lane);
 }
 
-// Amat[(o * nvw + vi)][k][j] bit p = bit k of (FFT(a) value at position p of value word (o, vi)) (x) 2^j; row 0 of Z
+// Amat[(o * nvw + vi)][j][k] bit p = bit k of (FFT(a) value at position p of value word (o, vi)) (x) 2^j; row 0 of Z
 __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64_t nvals, uint32_t *__restrict__ Amat) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (value word, k, j)
     if (idx >= nvals * 1024) return;
     const uint32_t vw = (uint32_t)(idx >> 10);
-    const uint32_t k = (idx >> 5) & 31, j = idx & 31;
+    const uint32_t j = (idx >> 5) & 31, k = idx & 31;
     const uint32_t nvw = 1u << (d.nb - 5);
     const uint32_t w = tile_base(d, vw / nvw) | tile_word(d, (vw % nvw) << 5);
     uint32_t mm = 0;
@@ -872,74 +919,109 @@ static inline uint32_t ilog2(uint64_t x) {
     return l;
 }
 
-// monomial <-> novel basis conversion of the 2^ell_elems low coefficients of every row, on bufs[cur]; phases with
-// chunk > 2^16 go through k_conv_top (fused) or the generic one-phase kernel (ping-pong), the rest through the
-// fused LDS tile kernel (in place). Returns the buffer index holding the result.
-static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse) {
+// monomial <-> novel basis conversion of the 2^ell_elems low coefficients of every row, on bufs[cur].
+// Phase list (gf2fft_model.conversion_phases) = [Taylor phases at x^(2^16)+x] [whole-unit phases] [phases local to a
+// 2^16 unit]; the last two groups commute. Taylor phases: k_conv_taylor (groups A and B, out of place), whole-unit
+// phases: inside the top butterfly pass when `units_in_top`, local phases: k_conv_tile (in place). Anything the
+// fused kernels do not cover goes through the generic one-phase kernel. Returns the buffer index of the result.
+static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid, uint32_t &ncol) {
+    memset(&t, 0, sizeof t);
+    int lrq = 3;
+    if (!groupA) {
+        t.lus = 16;
+        t.lnu = R < 5 ? R : 5;
+        t.hw = 1;
+        t.lnc = 10 - t.lnu;
+        for (int pb = (int)t.lnu - 1; pb >= 0; pb--) {
+            t.lchunk[t.nph] = (uint8_t)(pb + 17);
+            t.lpw[t.nph] = (uint8_t)pb;
+            t.nph++;
+        }
+    } else {
+        if (R <= 5) return false;
+        t.lus = 21;
+        t.lnu = R - 5;
+        t.hw = 1u << t.lnu;
+        int lnc = 10 - (int)t.lnu;
+        while (lnc < 0 || (1u << lnc) < 2 * t.hw) {
+            lrq--;
+            lnc++;
+        }
+        if (lrq < 0) return false;
+        t.lnc = (uint32_t)lnc;
+        for (int pb = (int)R - 1; pb >= 5; pb--) {
+            t.lchunk[t.nph] = (uint8_t)(pb + 17);
+            t.lpw[t.nph] = (uint8_t)pb;
+            t.nph++;
+        }
+    }
+    t.lrq = (uint32_t)lrq;
+    const uint32_t UW = 1u << (t.lus - 5), W = (1u << t.lnc) - t.hw;
+    ncol = (UW + W - 1) / W;
+    const uint32_t groups = 1u << (R - (groupA ? R : t.lnu));
+    grid = groups * ncol * (32u >> t.lrq);
+    return true;
+}
+
+static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse, bool units_in_top) {
     const uint64_t nwords = 1ull << (ell_elems - 5);
     std::vector<phase_t> ph;
     conv_rec(ph, ell_elems, 1);
     const uint32_t tb = ell_elems < 16 ? ell_elems : 16;
-    std::vector<phase_t> big;
+    std::vector<phase_t> taylor, units;
     conv_phases small;
     small.n = 0;
     for (auto &p : ph) {
         if (p.chunk > (1ull << tb)) {
-            big.push_back(p);  // conv_rec emits every chunk > 2^16 phase before the tile-local ones
+            (p.pw < (1ull << tb) ? taylor : units).push_back(p);
         } else {
             small.lchunk[small.n] = (uint8_t)ilog2(p.chunk);
             small.lpw[small.n] = (uint8_t)ilog2(p.pw);
             small.n++;
         }
     }
-    const uint64_t total = nwords * ROWS;
-    const unsigned grid = gridn(total, 256, 1u << 20);
+    const unsigned grid = gridn(nwords * ROWS, 256, 1u << 20);
     const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * 8);
     const int kid = inverse ? KID_CONV_INV : KID_CONV_FWD;
     const int kid_t = inverse ? KID_CONV_INV_TILE : KID_CONV_FWD_TILE;
-    conv_phases top;
-    top.n = 0;
-    bool top_ok = !big.empty() && ell_elems > 16 && ell_elems - 16 <= 7 && !getenv("SOT_NO_TOP");
-    uint32_t shift_sum = 0;
-    for (auto &p : big) {
-        uint32_t lpw = ilog2(p.pw);
-        if (lpw >= 5 && lpw < 16) top_ok = false;
-        if (lpw < 5) shift_sum += 1u << lpw;
-        if (top.n < 48) {
-            top.lchunk[top.n] = (uint8_t)ilog2(p.chunk);
-            top.lpw[top.n] = (uint8_t)lpw;
-            top.n++;
-        } else {
-            top_ok = false;
-        }
-    }
-    if (shift_sum > 31) top_ok = false;
-    const uint32_t lnu = top_ok ? ell_elems - 16 : 0;
-    const uint32_t NC = top_ok ? 1024u >> lnu : 0;  // NU * NC * 32 rows = 32768 words
-    const unsigned topgrid = top_ok ? (unsigned)(((2048 + NC - 2) / (NC - 1)) * 4) : 0;
-    if (!inverse) {
-        if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<1>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 0);
+    const uint32_t R = ell_elems > 16 ? ell_elems - 16 : 0;
+    taylor_desc tA, tB;
+    unsigned gA = 0, gB = 0;
+    uint32_t ncA = 0, ncB = 0;
+    const bool fused = R >= 1 && !getenv("SOT_NO_TOP");
+    const bool haveB = fused && make_taylor(R, false, tB, gB, ncB);
+    const bool needA = R > 5;
+    const bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA);
+    const bool fusedT = haveB && (!needA || haveA);
+    auto generic = [&](const std::vector<phase_t> &v) {
+        for (size_t q = 0; q < v.size(); q++) {
+            const phase_t &p = inverse ? v[v.size() - 1 - q] : v[q];
+            SOT_LAUNCH(c, kid, k_conv_phase<1>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords, p.chunk, p.pw,
+                       p.half, inverse ? 1 : 0);
             cur ^= 1;
-        } else {
-            for (size_t i = 0; i < big.size(); i++) {
-                SOT_LAUNCH(c, kid, k_conv_phase<1>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
-                           big[i].chunk, big[i].pw, big[i].half, 0);
-                cur ^= 1;
-            }
         }
+    };
+    auto run_taylor = [&](const taylor_desc &t, unsigned g, uint32_t nc) {
+        SOT_LAUNCH(c, kid, k_conv_taylor, dim3(g), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], t, nc, inverse ? 1 : 0);
+        cur ^= 1;
+    };
+    if (!inverse) {
+        if (fusedT) {
+            if (haveA) run_taylor(tA, gA, ncA);
+            run_taylor(tB, gB, ncB);
+        } else {
+            generic(taylor);
+        }
+        if (!units_in_top) generic(units);
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
-        if (top_ok) {
-            SOT_LAUNCH(c, kid, k_conv_top<1>, dim3(topgrid), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], lnu, ilog2(NC), top, 1);
-            cur ^= 1;
+        if (!units_in_top) generic(units);
+        if (fusedT) {
+            run_taylor(tB, gB, ncB);
+            if (haveA) run_taylor(tA, gA, ncA);
         } else {
-            for (size_t i = big.size(); i-- > 0;) {
-                SOT_LAUNCH(c, kid, k_conv_phase<1>, dim3(grid), dim3(256), bufs[cur], bufs[cur ^ 1], nwords,
-                           big[i].chunk, big[i].pw, big[i].half, 1);
-                cur ^= 1;
-            }
+            generic(taylor);
         }
     }
     return cur;
@@ -948,7 +1030,8 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
 // ---- tile descriptors of the butterfly passes (see fafft_model.py: level r <-> word-index bit m - r - 5)
 static inline bool is_pruned(uint32_t r) { return r == 1 || r == 2 || r == 4 || r == 8 || r == 16; }
 
-static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, const std::vector<uint32_t> &level_r) {
+static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, const std::vector<uint32_t> &level_r,
+                           const std::vector<uint32_t> &extra_wbits = {}) {
     // plane_r: pruned levels whose word bit is (or becomes, inside this pass) a plane bit, in plane-bit order;
     // level_r: levels run by this pass, in forward order (ascending r)
     tile_desc d;
@@ -960,10 +1043,11 @@ static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, con
     std::vector<uint32_t> bits_r = plane_r;
     for (uint32_t r : level_r)
         if (!is_pruned(r)) bits_r.push_back(r);
-    d.nb = (uint32_t)bits_r.size();
+    d.nb = (uint32_t)(bits_r.size() + extra_wbits.size());
     for (uint32_t j = 0; j < d.nb; j++) {
-        d.pos[j] = (uint8_t)wb(bits_r[j]);
-        d.tmask |= 1u << d.pos[j];
+        const uint32_t pos = j < bits_r.size() ? wb(bits_r[j]) : extra_wbits[j - bits_r.size()];
+        d.posq |= (uint64_t)pos << (5 * j);
+        d.tmask |= 1u << pos;
     }
     auto tbit_of = [&](uint32_t r) {
         for (uint32_t j = 0; j < d.nb; j++)
@@ -976,23 +1060,72 @@ static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, con
         uint32_t np = 0;
         for (uint32_t p : {1u, 2u, 4u, 8u, 16u})
             if (p < r) np++;
-        d.lev_r[d.nlev] = (uint8_t)r;
-        d.lev_tbit[d.nlev] = (uint8_t)tbit_of(r);
-        d.lev_np[d.nlev] = (uint8_t)np;
-        d.lev_pruned[d.nlev] = is_pruned(r);
-        d.nlev++;
+        d.lev[d.nlev++] = r | (tbit_of(r) << 8) | (np << 16) | ((is_pruned(r) ? 1u : 0u) << 24);
     }
     return d;
 }
 
 struct fft_plan {
     tile_desc top, mid1, mid2, low;
+    bool units_in_top;           // the whole-unit conversion phases run inside the top pass
+    unit_phases up_fwd, up_inv;  // for an operand (2^(m-1) coefficients) / for the product (2^m)
+    unit_phases up_none;
+    std::vector<uint32_t> list_fwd, list_inv;  // host copies of the move lists (uploaded once per context)
     std::vector<tile_desc> w32;  // extra 32-plane word-level passes (m > 25), forward order
 };
 
 static fft_plan make_plan(uint32_t m) {
     fft_plan p;
-    p.top = make_desc(m, {1, 2, 4, 8}, {1, 2, 3, 4, 5, 6, 7, 8});
+    // unit-index bits = word bits 11 .. m-6; the top pass owns word bits m-13 .. m-6
+    std::vector<uint32_t> extra;
+    for (uint32_t b = 11; b + 13 < m; b++) extra.push_back(b);
+    memset(&p.up_none, 0, sizeof p.up_none);
+    p.up_fwd = p.up_inv = p.up_none;
+    p.units_in_top = extra.size() <= 1 && !getenv("SOT_NO_TOP");
+    if (!p.units_in_top) extra.clear();
+    p.top = make_desc(m, {1, 2, 4, 8}, {1, 2, 3, 4, 5, 6, 7, 8}, extra);
+    if (p.units_in_top) {
+        // unit-index bit k (word bit 11 + k) -> tile bit; the remaining tile bits enumerate independent batches
+        uint32_t ub[16] = {0}, bb[16] = {0}, nbb = 0;
+        const uint32_t nub = m - 16;
+        for (uint32_t j = 0; j < p.top.nb; j++) {
+            const uint32_t pos = (uint32_t)(p.top.posq >> (5 * j)) & 31u;
+            if (pos >= 11)
+                ub[pos - 11] = j;
+            else
+                bb[nbb++] = j;
+        }
+        auto slot = [&](uint32_t u, uint32_t b) {
+            uint32_t sl = 0;
+            for (uint32_t k = 0; k < nub; k++) sl |= ((u >> k) & 1u) << ub[k];
+            for (uint32_t k = 0; k < nbb; k++) sl |= ((b >> k) & 1u) << bb[k];
+            return sl;
+        };
+        for (int inv = 0; inv < 2; inv++) {
+            const uint32_t nub_act = inv ? m - 16 : m - 17;  // an operand only fills the lower half of the units
+            std::vector<phase_t> ph;
+            conv_rec(ph, nub_act, 1);
+            std::vector<uint32_t> &list = inv ? p.list_inv : p.list_fwd;
+            unit_phases &u = inv ? p.up_inv : p.up_fwd;
+            for (size_t q = 0; q < ph.size(); q++) {
+                const phase_t &f = inv ? ph[ph.size() - 1 - q] : ph[q];
+                const uint32_t D = (uint32_t)(f.half - f.pw), nchunks = (1u << nub_act) / (uint32_t)f.chunk;
+                for (int step = 0; step < 2; step++) {
+                    const bool fold = inv ? step == 1 : step == 0;  // forward: fold then shift; inverse: shift then fold
+                    const uint32_t per = fold ? (uint32_t)f.pw : D;
+                    for (uint32_t cidx = 0; cidx < nchunks; cidx++)
+                        for (uint32_t jj = 0; jj < per; jj++)
+                            for (uint32_t b = 0; b < (1u << nbb); b++) {
+                                const uint32_t base = cidx * (uint32_t)f.chunk;
+                                const uint32_t dst = fold ? base + (uint32_t)f.half + jj : base + (uint32_t)f.pw + jj;
+                                const uint32_t src = fold ? base + (uint32_t)f.half + jj + D : base + (uint32_t)f.half + jj;
+                                list.push_back(slot(dst, b) | (slot(src, b) << 16));
+                            }
+                    u.step_end[u.nsteps++] = (uint32_t)list.size();
+                }
+            }
+        }
+    }
     p.mid1 = make_desc(m, {1, 2, 4, 8}, {9, 10, 11, 12});
     p.mid2 = make_desc(m, {1, 2, 4, 8, 16}, {13, 14, 15, 16});
     // 32-plane word levels r = 17 .. m-5; the lowest (up to 4) belong to the fused low kernel
@@ -1016,23 +1149,52 @@ static fft_plan make_plan(uint32_t m) {
 
 static inline unsigned tile_grid(const tile_desc &d) { return (unsigned)((1u << (d.m - 5 - d.nb)) * 2); }
 
+static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, uint32_t *Z, const unit_phases &up_in) {
+    tile_desc d = d_in;
+    unit_phases up = up_in;
+    if (getenv("SOT_DEBUG_NOLEVELS")) d.nlev = 0;
+    if (getenv("SOT_DEBUG_NOUNITS")) up.nsteps = 0;
+    if (const char *e = getenv("SOT_DEBUG_POS")) {  // experiment: synthetic tile bit positions, no compute
+        d.nlev = 0, up.nsteps = 0, d.tmask = 0, d.zero_bit = 32;
+        int mode = atoi(e);
+        d.posq = 0;
+        for (uint32_t j = 0; j < d.nb; j++) {
+            const uint32_t pos = mode == 0 ? j : mode == 1 ? (j < 4 ? j : j + 8) : (j < 4 ? j + 4 : j + 8);
+            d.posq |= (uint64_t)pos << (5 * j);
+            d.tmask |= 1u << pos;
+        }
+    }
+    const dim3 g(tile_grid(d)), b(TL_THREADS);
+    if (d.nb <= 8) {
+        if (inv)
+            SOT_LAUNCH(c, kid, (k_tile_fft<true, 8>), g, b, Z, d, c->TW, up);
+        else
+            SOT_LAUNCH(c, kid, (k_tile_fft<false, 8>), g, b, Z, d, c->TW, up);
+    } else {
+        if (inv)
+            SOT_LAUNCH(c, kid, (k_tile_fft<true, 9>), g, b, Z, d, c->TW, up);
+        else
+            SOT_LAUNCH(c, kid, (k_tile_fft<false, 9>), g, b, Z, d, c->TW, up);
+    }
+}
+
 // forward butterflies of an operand (upper half of the row zero) on Z, up to (not including) the low kernel
-static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
+static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int upto = 3) {
     tile_desc top = p.top;
     top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
-    SOT_LAUNCH(c, KID_FFT_TOP, (k_tile_fft<false, 8>), dim3(tile_grid(top)), dim3(TL_THREADS), Z, top, c->TW);
-    SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 8>), dim3(tile_grid(p.mid1)), dim3(TL_THREADS), Z, p.mid1, c->TW);
-    SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 8>), dim3(tile_grid(p.mid2)), dim3(TL_THREADS), Z, p.mid2, c->TW);
-    for (auto &d : p.w32)
-        SOT_LAUNCH(c, KID_FFT_MID, (k_tile_fft<false, 9>), dim3(tile_grid(d)), dim3(TL_THREADS), Z, d, c->TW);
+    launch_tile(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
+    if (upto >= 2) launch_tile(c, KID_FFT_MID, false, p.mid1, Z, p.up_none);
+    if (upto >= 3) {
+        launch_tile(c, KID_FFT_MID, false, p.mid2, Z, p.up_none);
+        for (auto &d : p.w32) launch_tile(c, KID_FFT_MID, false, d, Z, p.up_none);
+    }
 }
 
 static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
-    for (size_t i = p.w32.size(); i-- > 0;)
-        SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 9>), dim3(tile_grid(p.w32[i])), dim3(TL_THREADS), Z, p.w32[i], c->TW);
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 8>), dim3(tile_grid(p.mid2)), dim3(TL_THREADS), Z, p.mid2, c->TW);
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_tile_fft<true, 8>), dim3(tile_grid(p.mid1)), dim3(TL_THREADS), Z, p.mid1, c->TW);
-    SOT_LAUNCH(c, KID_IFFT_TOP, (k_tile_fft<true, 8>), dim3(tile_grid(p.top)), dim3(TL_THREADS), Z, p.top, c->TW);
+    for (size_t i = p.w32.size(); i-- > 0;) launch_tile(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
+    launch_tile(c, KID_IFFT_MID, true, p.mid2, Z, p.up_none);
+    launch_tile(c, KID_IFFT_MID, true, p.mid1, Z, p.up_none);
+    launch_tile(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
 static int upload_a_and_transform(sot_ctx *c) {
@@ -1064,12 +1226,12 @@ static int upload_a_and_transform(sot_ctx *c) {
     SOT_HIP(hipMemcpy(c->a2, ap.data(), ap.size() * 4, hipMemcpyHostToDevice));
     SOT_HIP(hipMemcpy(c->a_hi, c->a_hi_host.data(), c->a_hi_host.size() * 4, hipMemcpyHostToDevice));
     // FFT(a_lo): row 0 of Z
-    const fft_plan plan = make_plan(g.m);
+    const fft_plan &plan = *(const fft_plan *)c->qc_plan;
     SOT_HIP(hipMemsetAsync(c->Z0, 0, g.nw * ROWS * 4, c->stream));
     SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
     hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw / 2, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
     fft_forward_upper(c, zb[cur], plan);
     hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, zb[cur], plan.low, c->TW,
                        (const uint32_t *)nullptr);
@@ -1112,11 +1274,23 @@ int qc_init(sot_ctx *c) {
     SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 256 * 4));
     hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 256 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
     SOT_HIP(hipGetLastError());
+    fft_plan *plan = new fft_plan(make_plan(m));
+    c->qc_plan = plan;
+    if (plan->units_in_top) {
+        const size_t nf = plan->list_fwd.size(), ni = plan->list_inv.size();
+        SOT_TRY(dev_alloc(c, (void **)&c->up_list, (nf + ni + 1) * 4));
+        SOT_HIP(hipMemcpy(c->up_list, plan->list_fwd.data(), nf * 4, hipMemcpyHostToDevice));
+        SOT_HIP(hipMemcpy(c->up_list + nf, plan->list_inv.data(), ni * 4, hipMemcpyHostToDevice));
+        plan->up_fwd.list = c->up_list;
+        plan->up_inv.list = c->up_list + nf;
+    }
     return upload_a_and_transform(c);
 }
 
 void qc_free(sot_ctx *c) {
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC};
+    delete (fft_plan *)c->qc_plan;
+    c->qc_plan = nullptr;
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }
@@ -1128,7 +1302,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     blk_t *V = c->role[role].V;
     const uint64_t nb128 = cf.n_blocks * 128;
     const uint64_t nV = cf.cols * 128;
-    const fft_plan plan = make_plan(g.m);
+    const fft_plan &plan = *(const fft_plan *)c->qc_plan;
     if (role == SOT_ROLE_RECEIVER) {
         SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
         SOT_LAUNCH(c, KID_CLEAR_LSB, k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), V, nV);
@@ -1138,12 +1312,12 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
                g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
     fft_forward_upper(c, zb[cur], plan);
     SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), zb[cur], plan.low, c->TW,
                c->Amat);
     fft_inverse_upper(c, zb[cur], plan);
-    cur = run_conversion(c, zb, cur, g.m, true);
+    cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top);
     SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, LD_W)), dim3(256), zb[cur], g.nw, c->T);
     SOT_LAUNCH(c, KID_QC_FINAL, k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), V, nb128, cf.P, g.S, g.tail,
                        cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
@@ -1161,23 +1335,14 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
 int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out) {
     const qc_geom &g = c->g;
     SOT_HIP(hipSetDevice(c->device));
-    const fft_plan plan = make_plan(g.m);
+    const fft_plan &plan = *(const fft_plan *)c->qc_plan;
     SOT_HIP(hipMemsetAsync(c->Z0, 0, g.nw * ROWS * 4, c->stream));
     SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
     SOT_HIP(hipMemcpy2DAsync(c->Z0, ROWS * 4, row_in, 4, 4, g.nw / 2, hipMemcpyHostToDevice, c->stream));
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, stage >= 1 && plan.units_in_top);
     uint32_t *Z = zb[cur];
-    tile_desc top = plan.top;
-    top.zero_bit = 0;
-    if (stage >= 1) hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(top)), dim3(TL_THREADS), 0, c->stream, Z, top, c->TW);
-    if (stage >= 2)
-        hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(plan.mid1)), dim3(TL_THREADS), 0, c->stream, Z, plan.mid1, c->TW);
-    if (stage >= 3) {
-        hipLaunchKernelGGL((k_tile_fft<false, 8>), dim3(tile_grid(plan.mid2)), dim3(TL_THREADS), 0, c->stream, Z, plan.mid2, c->TW);
-        for (auto &d : plan.w32)
-            hipLaunchKernelGGL((k_tile_fft<false, 9>), dim3(tile_grid(d)), dim3(TL_THREADS), 0, c->stream, Z, d, c->TW);
-    }
+    if (stage >= 1) fft_forward_upper(c, Z, plan, stage);
     if (stage >= 4)
         hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, Z, plan.low, c->TW,
                            (const uint32_t *)nullptr);
