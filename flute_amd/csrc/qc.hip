@@ -716,43 +716,66 @@ __device__ __forceinline__ uint32_t lowmask(int i) {
     return i == 0 ? 0x55555555u : i == 1 ? 0x33333333u : i == 2 ? 0x0F0F0F0Fu : i == 3 ? 0x00FF00FFu : 0x0000FFFFu;
 }
 
+// a ? (c-selected) : bitfield insert  (c & a) | (~c & b)
+#define BFI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xE4)
+
+// One level on the value word W[32]. Only half of the bit positions of a plane hold y operands, so planes j and
+// j + 16 are packed into one word (y_j at the x positions, y_(j+16) at the y positions) and the 32x32 twiddle
+// matrix is applied with 16 x 32 mask words LMi[j][k] precomputed per (value word, level) by k_build_lowmasks:
+// bit p of LMi[j][k] = bit k of tau(p) (x) 2^j at x positions, of tau(p - 2^I) (x) 2^(j+16) at y positions,
+// uniform + per-position twiddle parts already combined. The masks arrive through scalar loads.
+// The compiler neither keeps these wave-uniform table reads on the scalar unit nor bounds their live ranges, so
+// they are issued explicitly: 16 dwords per s_load, waited for with lgkmcnt(0) (SMEM returns out of order) through
+// an asm that owns the destination registers, double-buffered so that the next row loads during the 32 XANDs.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define SLOAD32(lo, hi, ptr)                                                               \
+    do {                                                                                   \
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(lo) : "s"(ptr));               \
+        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(hi) : "s"(ptr));              \
+    } while (0)
+#define SWAIT32(lo, hi) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi))
+
+// acc[k] ^= v & row[k], k < 32, row = 32 consecutive mask words held in two SGPR tuples
+__device__ __forceinline__ void xand_row(uint32_t acc[32], uint32_t v, const u32x16 &lo, const u32x16 &hi) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], v, lo[k]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[16 + k] = XAND(acc[16 + k], v, hi[k]);
+}
+
+// acc[k] = XOR_j v[j] & M[j][k] for NJ rows of 32 masks at M (wave-uniform, 128-byte aligned)
+template <int NJ>
+__device__ __forceinline__ void apply_masks(uint32_t acc[32], const uint32_t v[NJ], const uint32_t *M) {
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0;
+    u32x16 a0, a1, b0, b1;
+    SLOAD32(a0, a1, M);
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+        SWAIT32(a0, a1);
+        SLOAD32(b0, b1, M + (j + 1) * 32);
+        xand_row(acc, v[j], a0, a1);
+        SWAIT32(b0, b1);
+        if (j + 2 < NJ) SLOAD32(a0, a1, M + (j + 2) * 32);
+        xand_row(acc, v[j + 1], b0, b1);
+    }
+}
+
 template <int I, bool INV>
-__device__ __forceinline__ void low_level(uint32_t W[32], uint32_t qw, const uint32_t *__restrict__ TW) {
+__device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
     const uint32_t A = lowmask(I);
     constexpr int SH = 1 << I;
-    uint32_t v[32];
     if (INV) {
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
     }
+    uint32_t P[16];
 #pragma unroll
-    for (int k = 0; k < 32; k++) v[k] = (W[k] >> SH) & A;  // y positions; the updates below touch x positions only
-    const uint32_t q = qw >> I;
+    for (int j = 0; j < 16; j++) P[j] = BFI(W[j] >> SH, W[j + 16], A);
+    uint32_t acc[32];
+    apply_masks<16>(acc, P, LMi);
 #pragma unroll
-    for (int k0 = 0; k0 < 32; k0 += 8) {
-        uint32_t rows[8];
-        tw_rows<8>(TW, q, k0, rows);
-        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) a[kk] = XAND(a[kk], v[j], 0u - ((rows[kk] >> j) & 1u));
-            __builtin_amdgcn_sched_barrier(0);  // keep the scalar mask extraction next to its use (SGPR pressure)
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) W[k0 + kk] ^= a[kk];
-    }
-    if (I < 4) {
-#pragma unroll
-        for (int blk = 0; blk < 4; blk++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                uint32_t a = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) a = XAND(a, v[blk * 8 + j], d_MPOS[(I * 8 + k) * 8 + j]);
-                W[blk * 8 + k] ^= a;
-            }
-    }
+    for (int k = 0; k < 32; k++) W[k] = XAND(W[k], acc[k] ^ (acc[k] >> SH), A);
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
@@ -764,7 +787,8 @@ __device__ __forceinline__ void low_level(uint32_t W[32], uint32_t qw, const uin
 // Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
 template <int MODE>
 __global__ void __launch_bounds__(TL_THREADS)
-    k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ Amat) {
+    k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ LM,
+              const uint32_t *__restrict__ Amat) {
     __shared__ uint32_t lds[512 * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -777,35 +801,26 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t nvw = 1u << (d.nb - 5);  // value words in the tile
     for (uint32_t vi = wave; vi < nvw; vi += TL_WAVES) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
-        const uint32_t w = base_w | tile_word(d, vi << 5);
-        const uint32_t qw = (1u << d.m) | ((w & ~d.pmw) << 5);
+        const uint64_t vw = (uint64_t)o * nvw + vi;  // wave-uniform
+        const uint32_t *L = LM + vw * (5 * 512);
         uint32_t W[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
-        low_level<4, false>(W, qw, TW);
-        low_level<3, false>(W, qw, TW);
-        low_level<2, false>(W, qw, TW);
-        low_level<1, false>(W, qw, TW);
-        low_level<0, false>(W, qw, TW);
+        low_level<4, false>(W, L + 4 * 512);
+        low_level<3, false>(W, L + 3 * 512);
+        low_level<2, false>(W, L + 2 * 512);
+        low_level<1, false>(W, L + 1 * 512);
+        low_level<0, false>(W, L);
         if (MODE == 1) {
-            // Amat[value word][j][k]: for every input plane j the 32 output masks are contiguous (2 x s_load_dwordx16)
-            const uint32_t *M = (const uint32_t *)__builtin_assume_aligned(Amat + ((uint64_t)o * nvw + vi) * 1024, 128);
             uint32_t t[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) t[k] = 0;
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-#pragma unroll
-                for (int k = 0; k < 32; k++) t[k] = XAND(t[k], W[j], M[j * 32 + k]);
-                if (j & 1) __builtin_amdgcn_sched_barrier(0);  // bounds the SGPRs holding masks to two rows
-            }
+            apply_masks<32>(t, W, Amat + vw * 1024);  // Amat[value word][j][k]
 #pragma unroll
             for (int k = 0; k < 32; k++) W[k] = t[k];
-            low_level<0, true>(W, qw, TW);
-            low_level<1, true>(W, qw, TW);
-            low_level<2, true>(W, qw, TW);
-            low_level<3, true>(W, qw, TW);
-            low_level<4, true>(W, qw, TW);
+            low_level<0, true>(W, L);
+            low_level<1, true>(W, L + 1 * 512);
+            low_level<2, true>(W, L + 2 * 512);
+            low_level<3, true>(W, L + 3 * 512);
+            low_level<4, true>(W, L + 4 * 512);
         }
 #pragma unroll
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
@@ -813,6 +828,28 @@ __global__ void __launch_bounds__(TL_THREADS)
     __syncthreads();
     if (MODE == 1) tile_levels<true>(lds, d, base_w, TW, wave, lane);
     tile_store<9>(lds, Z, d, base_w, rh, wave, lane);
+}
+
+// LM[((value word * 5 + i) * 16 + j) * 32 + k]: the packed twiddle masks of intra-word level i (see low_level)
+__global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__restrict__ TW, uint32_t *__restrict__ LM) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvals * 5 * 512) return;
+    const uint32_t k = idx & 31, j = (idx >> 5) & 15;
+    const uint32_t li = (uint32_t)((idx >> 9) % 5);
+    const uint32_t vw = (uint32_t)(idx / (5 * 512));
+    const uint32_t nvw = 1u << (d.nb - 5);
+    const uint32_t w = tile_base(d, vw / nvw) | tile_word(d, (vw % nvw) << 5);
+    const uint32_t q = ((1u << d.m) | ((w & ~d.pmw) << 5)) >> li;
+    uint32_t rw[1];
+    tw_rows<1>(TW, q, k, rw);
+    uint32_t mask = 0;
+    for (uint32_t p = 0; p < 32; p++) {
+        const uint32_t e = (p & ~(1u << li)) >> li;  // per-position twiddle index of the pair's x position
+        const uint32_t R = rw[0] ^ TW[(e << 5) + k];
+        const uint32_t jj = ((p >> li) & 1u) ? j + 16 : j;
+        mask |= ((R >> jj) & 1u) << p;
+    }
+    LM[idx] = mask;
 }
 
 // Amat[(o * nvw + vi)][j][k] bit p = bit k of (FFT(a) value at position p of value word (o, vi)) (x) 2^j; row 0 of Z
@@ -1233,8 +1270,10 @@ static int upload_a_and_transform(sot_ctx *c) {
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
     fft_forward_upper(c, zb[cur], plan);
+    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * 512, 256)), dim3(256), 0, c->stream, plan.low,
+                       g.nw / 32, c->TW, c->LM);
     hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, zb[cur], plan.low, c->TW,
-                       (const uint32_t *)nullptr);
+                       c->LM, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * 1024, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
                        g.nw / 32, c->Amat);
     SOT_HIP(hipGetLastError());
@@ -1267,6 +1306,7 @@ int qc_init(sot_ctx *c) {
     SOT_TRY(dev_alloc(c, (void **)&c->Z0, g.nw * ROWS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->Z1, g.nw * ROWS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * 1024 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * 512 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->T, 2 * g.S * 16));
     SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
@@ -1290,7 +1330,7 @@ int qc_init(sot_ctx *c) {
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }
@@ -1315,7 +1355,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
     fft_forward_upper(c, zb[cur], plan);
     SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), zb[cur], plan.low, c->TW,
-               c->Amat);
+               c->LM, c->Amat);
     fft_inverse_upper(c, zb[cur], plan);
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top);
     SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, LD_W)), dim3(256), zb[cur], g.nw, c->T);
@@ -1345,7 +1385,7 @@ int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_ou
     if (stage >= 1) fft_forward_upper(c, Z, plan, stage);
     if (stage >= 4)
         hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, Z, plan.low, c->TW,
-                           (const uint32_t *)nullptr);
+                           c->LM, (const uint32_t *)nullptr);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipMemcpy2DAsync(row_out, 4, Z, ROWS * 4, 4, g.nw, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
