@@ -782,6 +782,120 @@ __device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K4m: the 16-plane passes (levels 9..12 and 13..16). Tile = 16 values x 16 planes x 64 rows, slot = lv * 16 + plane,
+// lv bit b <-> level rmin + b. One wave per butterfly and level (8 waves), all 16 planes in registers, twiddle
+// matrices as precomputed mask words MT[outer][b][butterfly][j][k] (k_build_midmasks) read through the scalar unit.
+#define MD_THREADS 512
+#define MD_WAVES (MD_THREADS / 64)
+
+__device__ __forceinline__ uint32_t pext32(uint32_t v, uint32_t mask) {
+    uint32_t r = 0, o = 0;
+    for (uint32_t b = 0; b < 27; b++)
+        if ((mask >> b) & 1u) r |= ((v >> b) & 1u) << o++;
+    return r;
+}
+__device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < 27; b++)
+        if ((mask >> b) & 1u) {
+            r |= (v & 1u) << b;
+            v >>= 1;
+        }
+    return r;
+}
+
+// acc[k] ^= XOR_j y[j] & M[j][k], j, k < 16; M wave-uniform, 128-byte aligned, two rows per pair of tuples
+__device__ __forceinline__ void apply_masks16(uint32_t acc[16], const uint32_t y[16], const uint32_t *M) {
+    u32x16 a0, a1, b0, b1;
+    SLOAD32(a0, a1, M);
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        SWAIT32(a0, a1);
+        SLOAD32(b0, b1, M + (j + 2) * 16);
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j], a0[k]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 1], a1[k]);
+        SWAIT32(b0, b1);
+        if (j + 4 < 16) SLOAD32(a0, a1, M + (j + 4) * 16);
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 2], b0[k]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 3], b1[k]);
+    }
+}
+
+template <bool INV, bool PRUNE_LAST>
+__global__ void __launch_bounds__(MD_THREADS)
+    k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT) {
+    __shared__ uint32_t lds[256 * TL_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rh = blockIdx.x & 1;
+    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
+    {
+        constexpr int PER = 256 / MD_WAVES;
+        const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+        uint32_t v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) v[i] = g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS];
+#pragma unroll
+        for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
+    }
+    const uint32_t outer = pext32(base_w, mask_hi);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = INV ? 3 - q : q;
+        const bool pruned = PRUNE_LAST && b == 3;
+        const uint32_t bf = wave;
+        const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
+        uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
+        uint32_t *py = px + (16u << b) * TL_ROWS;
+        const uint32_t *M = MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8);
+        uint32_t x[16], y[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            x[k] = px[k * TL_ROWS];
+            y[k] = py[k * TL_ROWS];
+        }
+        if (INV && !pruned) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) y[k] ^= x[k];
+        }
+        apply_masks16(x, y, M);
+#pragma unroll
+        for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
+        if (!pruned) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) py[k * TL_ROWS] = INV ? y[k] : y[k] ^ x[k];
+        }
+        __syncthreads();
+    }
+    {
+        constexpr int PER = 256 / MD_WAVES;
+        uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+#pragma unroll
+        for (int i = 0; i < PER; i++) g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS] = lds[(wave + MD_WAVES * i) * TL_ROWS + lane];
+    }
+}
+
+// MT[((outer * 4 + b) * 8 + bf)][j][k] = all-ones iff output plane k of (twiddle (x) y) takes input plane j
+__global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, uint32_t nouter,
+                                 const uint32_t *__restrict__ TW, uint32_t *__restrict__ MT) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (outer, b, bf, j)
+    if (idx >= nouter * 4 * 8 * 16) return;
+    const uint32_t j = idx & 15, bf = (idx >> 4) & 7, b = (idx >> 7) & 3, outer = idx >> 9;
+    const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
+    const uint32_t w = pdep32(outer, mask_hi) | tile_word(d, lvx << 4);
+    const uint32_t r = rmin + b;
+    const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
+    uint32_t rows[16];
+    tw_rows<16>(TW, q, 0, rows);
+    for (uint32_t k = 0; k < 16; k++) MT[(uint64_t)idx * 16 + k] = 0u - ((rows[k] >> j) & 1u);
+}
+
 // K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
 // pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
 // Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
@@ -916,6 +1030,106 @@ __global__ void __launch_bounds__(256)
                         blk_t u = ld_v1p(V1, nb128, P, S + j);
                         r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
                     }
+                }
+            }
+        }
+        out[k] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 fused with K9: product rows -> Blocks, fold mod x^P - 1, add V0 and the tail terms, in one pass (no T):
+//   B[k] = V0[k] ^ V0[k+P] ^ C[k] ^ C[k+P] ^ sum_{i: a_hi[i]} V1'[(q - i) mod P] ^ sum_{j < tail} a_lo[(q - j) mod P] V1'[S + j]
+// with C = a_lo * V1'_lo (bit rows in Z, C has fewer than 2 min(P, S) bits) and q = (k - S) mod P.
+// One workgroup = FN_W words = 512 consecutive k. The row words of C[k] and C[k+P] are combined before the 32x32
+// transposes (P is odd: a funnel shift of two words); the tail sums read a window of V1' and of a' staged in LDS
+// (index x = (k - k0) + (tail - 1 - i) for both).
+#define FN_W 16
+#define FN_K (FN_W * 32)
+#define FN_TAILMAX 256
+__global__ void __launch_bounds__(256)
+    k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, uint64_t nb128, uint64_t P,
+                uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2, const uint32_t *__restrict__ a_hi,
+                blk_t *__restrict__ out) {
+    __shared__ uint32_t tin[FN_W * 129];   // [w][row]
+    __shared__ uint32_t tout[FN_W * 132];  // [w][p][q]
+    __shared__ blk_t win[FN_K + FN_TAILMAX];   // V1'[(c0 + x) mod P]
+    __shared__ blk_t hi[FN_TAILMAX];           // V1'[S + j]
+    __shared__ uint8_t abit[FN_K + FN_TAILMAX];  // a_lo[(c0 + x) mod P]
+    const blk_t *V1 = V + nb128;
+    const uint64_t k0 = (uint64_t)blockIdx.x * FN_K;
+    const uint64_t w0 = k0 >> 5;
+    const uint64_t wsh = P >> 5;
+    const uint32_t sh = (uint32_t)(P & 31);
+    for (uint32_t i = threadIdx.x; i < FN_W * ROWS; i += 256) {
+        const uint64_t w = w0 + (i >> 7);
+        const uint32_t row = i & 127;
+        uint32_t v = 0;
+        if (w < nw) v = Z[w * ROWS + row];
+        const uint64_t w1 = w + wsh;
+        if (w1 < nw) {
+            uint32_t lo = Z[w1 * ROWS + row];
+            uint32_t hi1 = (sh && w1 + 1 < nw) ? Z[(w1 + 1) * ROWS + row] : 0u;
+            v ^= sh ? ((lo >> sh) | (hi1 << (32 - sh))) : lo;
+        }
+        tin[(i >> 7) * 129 + row] = v;
+    }
+    uint64_t c0 = 0;
+    if (tail) {
+        const uint64_t q0 = k0 >= S ? k0 - S : k0 + P - S;  // k0 < n <= P
+        c0 = (q0 + P - (tail - 1)) % P;
+        for (uint32_t x = threadIdx.x; x < FN_K + tail - 1; x += 256) {
+            uint64_t cc = c0 + x;
+            if (cc >= P) cc -= P;
+            blk_t v = V1[cc];
+            if (cc + P < nb128) {
+                blk_t u = V1[cc + P];
+                v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
+            }
+            win[x] = v;
+            abit[x] = cc < S ? (uint8_t)((a2[cc >> 5] >> (cc & 31)) & 1u) : (uint8_t)0;
+        }
+        for (uint32_t j = threadIdx.x; j < tail; j += 256) {
+            blk_t v = V1[S + j];
+            if (S + j + P < nb128) {
+                blk_t u = V1[S + j + P];
+                v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
+            }
+            hi[j] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < FN_W * 4) {
+        const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
+        uint32_t a[32];
+#pragma unroll
+        for (int b = 0; b < 32; b++) a[b] = tin[wl * 129 + 32 * q + b];
+        transpose32(a);
+#pragma unroll
+        for (int p = 0; p < 32; p++) tout[wl * 132 + p * 4 + q] = a[p];
+    }
+    __syncthreads();
+    for (uint32_t kl = threadIdx.x; kl < FN_K; kl += 256) {
+        const uint64_t k = k0 + kl;
+        if (k >= n) break;
+        const uint32_t *sp = tout + (kl >> 5) * 132 + (kl & 31) * 4;
+        blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        blk_t u = V[k];
+        r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+        if (k + P < nb128) {
+            u = V[k + P];
+            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+        }
+        if (tail) {
+            const uint32_t xb = kl + tail - 1;  // x = xb - i
+            for (uint32_t i = 0; i < tail; i++) {
+                if ((a_hi[i >> 5] >> (i & 31)) & 1u) {  // wave-uniform
+                    u = win[xb - i];
+                    r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+                }
+                if (abit[xb - i]) {
+                    u = hi[i];
+                    r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
                 }
             }
         }
@@ -1104,6 +1318,7 @@ static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, con
 
 struct fft_plan {
     tile_desc top, mid1, mid2, low;
+    uint32_t mid1_hi, mid2_hi;   // word bits (outside the tile) that the twiddles of the pass depend on
     bool units_in_top;           // the whole-unit conversion phases run inside the top pass
     unit_phases up_fwd, up_inv;  // for an operand (2^(m-1) coefficients) / for the product (2^m)
     unit_phases up_none;
@@ -1163,8 +1378,13 @@ static fft_plan make_plan(uint32_t m) {
             }
         }
     }
+    // 16-plane passes (k_mid): tile bits = 4 plane bits, then the 4 level bits in level order
     p.mid1 = make_desc(m, {1, 2, 4, 8}, {9, 10, 11, 12});
-    p.mid2 = make_desc(m, {1, 2, 4, 8, 16}, {13, 14, 15, 16});
+    p.mid2 = make_desc(m, {1, 2, 4, 8}, {13, 14, 15}, {m - 16 - 5});
+    p.mid1_hi = p.mid2_hi = 0;
+    for (uint32_t r : {3u, 5u, 6u, 7u}) p.mid1_hi |= 1u << (m - r - 5);
+    p.mid2_hi = p.mid1_hi;
+    for (uint32_t r : {9u, 10u, 11u, 12u}) p.mid2_hi |= 1u << (m - r - 5);
     // 32-plane word levels r = 17 .. m-5; the lowest (up to 4) belong to the fused low kernel
     const uint32_t last = m - 5;
     uint32_t nlow = last >= 17 ? last - 16 : 0;
@@ -1220,17 +1440,18 @@ static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int up
     tile_desc top = p.top;
     top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
     launch_tile(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
-    if (upto >= 2) launch_tile(c, KID_FFT_MID, false, p.mid1, Z, p.up_none);
+    if (upto >= 2)
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
     if (upto >= 3) {
-        launch_tile(c, KID_FFT_MID, false, p.mid2, Z, p.up_none);
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(tile_grid(p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2);
         for (auto &d : p.w32) launch_tile(c, KID_FFT_MID, false, d, Z, p.up_none);
     }
 }
 
 static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
     for (size_t i = p.w32.size(); i-- > 0;) launch_tile(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
-    launch_tile(c, KID_IFFT_MID, true, p.mid2, Z, p.up_none);
-    launch_tile(c, KID_IFFT_MID, true, p.mid1, Z, p.up_none);
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(tile_grid(p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2);
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
     launch_tile(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
@@ -1316,6 +1537,13 @@ int qc_init(sot_ctx *c) {
     SOT_HIP(hipGetLastError());
     fft_plan *plan = new fft_plan(make_plan(m));
     c->qc_plan = plan;
+    SOT_TRY(dev_alloc(c, (void **)&c->MT1, 16ull * 4 * 8 * 256 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->MT2, 256ull * 4 * 8 * 256 * 4));
+    hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
+                       16u, c->TW, c->MT1);
+    hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
+                       13u, 256u, c->TW, c->MT2);
+    SOT_HIP(hipGetLastError());
     if (plan->units_in_top) {
         const size_t nf = plan->list_fwd.size(), ni = plan->list_inv.size();
         SOT_TRY(dev_alloc(c, (void **)&c->up_list, (nf + ni + 1) * 4));
@@ -1330,7 +1558,7 @@ int qc_init(sot_ctx *c) {
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }
@@ -1358,9 +1586,12 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
                c->LM, c->Amat);
     fft_inverse_upper(c, zb[cur], plan);
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top);
-    SOT_LAUNCH(c, KID_QC_STORE, k_qc_store, dim3(gridn(g.nw, LD_W)), dim3(256), zb[cur], g.nw, c->T);
-    SOT_LAUNCH(c, KID_QC_FINAL, k_qc_final, dim3(gridn(cf.n, 256, 8192)), dim3(256), V, nb128, cf.P, g.S, g.tail,
-                       cf.n, c->T, 2 * g.S, c->a2, c->a_hi, c->role[role].enc);
+    if (g.tail > FN_TAILMAX) {
+        sot_set_error("internal: tail exceeds FN_TAILMAX");
+        return SOT_EINVAL;
+    }
+    SOT_LAUNCH(c, KID_QC_FINAL, k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), zb[cur], g.nw, V, nb128, cf.P, g.S,
+               (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[role].encoded = true;
