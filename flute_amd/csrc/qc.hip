@@ -783,6 +783,116 @@ __device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4t: the top pass: whole-unit conversion phases + levels 1..8 (1 and 2 only relabel bits as planes).
+// Tile bits: t0..t3 = planes (levels 1, 2, 4, 8), t4..t7 = levels 3, 5, 6, 7, t8 = an extra unit-index bit (m = 25).
+// The six real levels run as three register rounds of two levels each; in a round every wave owns whole groups of
+// slots (all planes x the two pair bits of the round), so one barrier per round is enough.
+template <int K, bool INV>
+__device__ __forceinline__ void reg_bfly(uint32_t x[K], uint32_t y[K], const uint32_t *__restrict__ TW, uint32_t q,
+                                         bool pruned) {
+    uint32_t rows[K];
+    tw_rows<K>(TW, q, 0, rows);
+    if (INV && !pruned) {
+#pragma unroll
+        for (int k = 0; k < K; k++) y[k] ^= x[k];
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) x[k] = XAND(x[k], y[j], 0u - ((rows[k] >> j) & 1u));
+    }
+    if (!INV && !pruned) {
+#pragma unroll
+        for (int k = 0; k < K; k++) y[k] ^= x[k];
+    }
+}
+
+// one round: group slots = base | p | (a << ba) | (b << bb), p < K planes; level 1 pairs bit a, level 2 pairs bit b
+// (forward order). q1(b) and q2(a) give the twiddle indices (they may depend on the other pair bit of the round).
+template <int K, bool INV, class Q1, class Q2>
+__device__ __forceinline__ void top_round(uint32_t *lds, uint32_t base, uint32_t ba, uint32_t bb, bool pruned2,
+                                          const uint32_t *__restrict__ TW, uint32_t lane, Q1 q1, Q2 q2) {
+    uint32_t v[2][2][K];  // [b][a][plane]
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int p = 0; p < K; p++) v[b][a][p] = lds[(base | p | (a << ba) | (b << bb)) * TL_ROWS + lane];
+    if (!INV) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) reg_bfly<K, false>(v[b][0], v[b][1], TW, q1(b), false);
+#pragma unroll
+        for (int a = 0; a < 2; a++) reg_bfly<K, false>(v[0][a], v[1][a], TW, q2(a), pruned2);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; a++) reg_bfly<K, true>(v[0][a], v[1][a], TW, q2(a), pruned2);
+#pragma unroll
+        for (int b = 0; b < 2; b++) reg_bfly<K, true>(v[b][0], v[b][1], TW, q1(b), false);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int p = 0; p < K; p++) lds[(base | p | (a << ba) | (b << bb)) * TL_ROWS + lane] = v[b][a][p];
+}
+
+template <bool INV>
+__device__ __forceinline__ void top_levels(uint32_t *lds, uint32_t nb, const uint32_t *__restrict__ TW, uint32_t wave,
+                                           uint32_t lane) {
+    const uint32_t nx = nb - 8;  // extra tile bits above t7
+    for (int rnd = 0; rnd < 3; rnd++) {
+        const int R = INV ? 2 - rnd : rnd;
+        if (R == 0) {
+            // levels 3 (pair bit t4) and 4 (pair bit t2, pruned), K = 4; free bits: t3, t5, t6, t7, extras
+            const uint32_t ngroups = 16u << nx;
+            for (uint32_t g = wave; g < ngroups; g += TL_WAVES) {
+                const uint32_t base = ((g & 1u) << 3) | ((g >> 1) << 5);
+                top_round<4, INV>(lds, base, 4, 2, true, TW, lane, [&](int) { return 8u; },
+                                  [&](int a) { return 16u | ((uint32_t)a << 1); });
+            }
+        } else if (R == 1) {
+            // levels 5 (t5) and 6 (t6), K = 8; free bits: t3, t4, t7, extras
+            const uint32_t ngroups = 8u << nx;
+            for (uint32_t g = wave; g < ngroups; g += TL_WAVES) {
+                const uint32_t j3 = (g >> 1) & 1u;
+                const uint32_t base = ((g & 1u) << 3) | (j3 << 4) | ((g >> 2) << 7);
+                top_round<8, INV>(lds, base, 5, 6, false, TW, lane, [&](int) { return 32u | (j3 << 2); },
+                                  [&](int a) { return 64u | (j3 << 3) | ((uint32_t)a << 1); });
+            }
+        } else {
+            // levels 7 (t7) and 8 (t3, pruned), K = 8; free bits: t4, t5, t6, extras
+            const uint32_t ngroups = 8u << nx;
+            for (uint32_t g = wave; g < ngroups; g += TL_WAVES) {
+                const uint32_t j3 = g & 1u, j5 = (g >> 1) & 1u, j6 = (g >> 2) & 1u;
+                const uint32_t base = ((g & 7u) << 4) | ((g >> 3) << 8);
+                const uint32_t qc = (j3 << 4) | (j5 << 2) | (j6 << 1);
+                top_round<8, INV>(lds, base, 7, 3, true, TW, lane, [&](int) { return 128u | qc; },
+                                  [&](int a) { return 256u | (qc << 1) | ((uint32_t)a << 1); });
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool INV, int NB>
+__global__ void __launch_bounds__(TL_THREADS)
+    k_top(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, unit_phases up) {
+    __shared__ uint32_t lds[(1 << NB) * TL_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rh = blockIdx.x & 1;
+    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
+    tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
+    __syncthreads();
+    if (!INV && up.nsteps) tile_unit_phases(lds, up);
+    top_levels<INV>(lds, d.nb, TW, wave, lane);
+    if (INV && up.nsteps) tile_unit_phases(lds, up);
+    tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4m: the 16-plane passes (levels 9..12 and 13..16). Tile = 16 values x 16 planes x 64 rows, slot = lv * 16 + plane,
 // lv bit b <-> level rmin + b. One wave per butterfly and level (8 waves), all 16 planes in registers, twiddle
 // matrices as precomputed mask words MT[outer][b][butterfly][j][k] (k_build_midmasks) read through the scalar unit.
@@ -896,6 +1006,70 @@ __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, u
     for (uint32_t k = 0; k < 16; k++) MT[(uint64_t)idx * 16 + k] = 0u - ((rows[k] >> j) & 1u);
 }
 
+// the 32-plane word levels of the low tile (slot = lv * 32 + plane, lv bit b <-> level m - 4 - nl + b): one wave per
+// (butterfly, half of the output planes); results stay in registers across the barrier that separates the reads
+// of a level from its writes.
+template <bool INV, int C0>
+__device__ __forceinline__ void low_word_item(const uint32_t *lds, uint32_t xs, uint32_t ys, const uint32_t *__restrict__ TW,
+                                              uint32_t q, uint32_t lane, uint32_t xn[16], uint32_t yn[16]) {
+    uint32_t rows[16];
+    tw_rows<16>(TW, q, C0, rows);
+    uint32_t y[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) y[j] = lds[(ys + j) * TL_ROWS + lane];
+    if (INV) {
+#pragma unroll
+        for (int j = 0; j < 32; j++) y[j] ^= lds[(xs + j) * TL_ROWS + lane];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) xn[kk] = lds[(xs + C0 + kk) * TL_ROWS + lane];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) xn[kk] = XAND(xn[kk], y[j], 0u - ((rows[kk] >> j) & 1u));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) yn[kk] = INV ? y[C0 + kk] : y[C0 + kk] ^ xn[kk];
+}
+
+template <bool INV>
+__device__ __forceinline__ void low_word_levels(uint32_t *lds, const tile_desc &d, uint32_t base_w,
+                                                const uint32_t *__restrict__ TW, uint32_t wave, uint32_t lane) {
+    const uint32_t nl = d.nb - 5;
+    if (nl == 0) return;
+    const uint32_t items = 1u << nl;  // 2^(nl-1) butterflies x 2 halves, <= 16
+    for (uint32_t qi = 0; qi < nl; qi++) {
+        const uint32_t b = INV ? nl - 1 - qi : qi;
+        uint32_t xn[16], yn[16];
+        uint32_t xs = 0, ys = 0;
+        const bool act = wave < items;
+        const uint32_t c0 = (wave & 1u) << 4;
+        if (act) {
+            const uint32_t bf = wave >> 1;
+            const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
+            xs = lvx << 5;
+            ys = xs + (32u << b);
+            const uint32_t w = base_w | tile_word(d, xs);
+            const uint32_t r = d.m - 4 - nl + b;  // the tile holds the lowest nl word levels (17..20 at m = 25)
+            const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
+            if (c0)
+                low_word_item<INV, 16>(lds, xs, ys, TW, q, lane, xn, yn);
+            else
+                low_word_item<INV, 0>(lds, xs, ys, TW, q, lane, xn, yn);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                lds[(xs + c0 + kk) * TL_ROWS + lane] = xn[kk];
+                lds[(ys + c0 + kk) * TL_ROWS + lane] = yn[kk];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
 // pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
 // Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
@@ -911,7 +1085,7 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t base_w = tile_base(d, o);
     tile_load<9>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
-    tile_levels<false>(lds, d, base_w, TW, wave, lane);
+    low_word_levels<false>(lds, d, base_w, TW, wave, lane);
     const uint32_t nvw = 1u << (d.nb - 5);  // value words in the tile
     for (uint32_t vi = wave; vi < nvw; vi += TL_WAVES) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
@@ -940,7 +1114,7 @@ __global__ void __launch_bounds__(TL_THREADS)
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
     }
     __syncthreads();
-    if (MODE == 1) tile_levels<true>(lds, d, base_w, TW, wave, lane);
+    if (MODE == 1) low_word_levels<true>(lds, d, base_w, TW, wave, lane);
     tile_store<9>(lds, Z, d, base_w, rh, wave, lane);
 }
 
@@ -1435,11 +1609,26 @@ static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, ui
     }
 }
 
+static void launch_top(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32_t *Z, const unit_phases &up) {
+    const dim3 g(tile_grid(d)), b(TL_THREADS);
+    if (d.nb <= 8) {
+        if (inv)
+            SOT_LAUNCH(c, kid, (k_top<true, 8>), g, b, Z, d, c->TW, up);
+        else
+            SOT_LAUNCH(c, kid, (k_top<false, 8>), g, b, Z, d, c->TW, up);
+    } else {
+        if (inv)
+            SOT_LAUNCH(c, kid, (k_top<true, 9>), g, b, Z, d, c->TW, up);
+        else
+            SOT_LAUNCH(c, kid, (k_top<false, 9>), g, b, Z, d, c->TW, up);
+    }
+}
+
 // forward butterflies of an operand (upper half of the row zero) on Z, up to (not including) the low kernel
 static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int upto = 3) {
     tile_desc top = p.top;
     top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
-    launch_tile(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
+    launch_top(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
     if (upto >= 2)
         SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
     if (upto >= 3) {
@@ -1452,7 +1641,7 @@ static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
     for (size_t i = p.w32.size(); i-- > 0;) launch_tile(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
     SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(tile_grid(p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2);
     SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
-    launch_tile(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
+    launch_top(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
 static int upload_a_and_transform(sot_ctx *c) {
