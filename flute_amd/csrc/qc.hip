@@ -354,6 +354,201 @@ __global__ void __launch_bounds__(CT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2u: the 32 phases local to a unit of 2^16 coefficients, tile = 2048 words x 16 rows (4 row quads), in three parts:
+//   P1  the 8 Taylor phases at x^256 + x (chunk 2^9 .. 2^16, shift 1 .. 128 bits): fold / shift steps in LDS;
+//   P2  the 12 phases that move whole 256-bit sub-units (conversion of the 256 sub-unit indices): a host-built list
+//       of (dst, src) sub-unit moves in hazard-free steps, 32 lanes per move;
+//   P3  the 12 phases inside a 256-bit sub-unit: in registers, thread = (sub-unit, row quad), 8 x u4, no barriers.
+// P2 and P3 commute. Forward = P1, P2, P3 (written to HBM straight from the registers); inverse = the reverse.
+// LDS index of (word, quad) = 36 * (word / 8) + 4 * (word % 8) + quad: 64 B of padding per sub-unit keeps the
+// 128-bit accesses of a quarter wave on distinct banks when threads own sub-units.
+#define UP_MAX_STEPS 64
+#define CU_LDS (2048 * 4 + 256 * 4)
+__device__ __forceinline__ uint32_t cu_idx(uint32_t word) { return (word << 2) + ((word >> 3) << 2); }
+
+__device__ __forceinline__ void cu_fold(u4 *lds, uint32_t lchunk, uint32_t lpw) {
+    const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
+    const uint32_t nchunks = 2048u >> (lchunk - 5);
+    if (lpw >= 5) {
+        const uint32_t pw_w = 1u << (lpw - 5);
+        const uint32_t items = nchunks * pw_w * 4;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & 3, wi = it >> 2;
+            uint32_t c = wi >> (lpw - 5), d = wi & (pw_w - 1);
+            uint32_t base = c * chunk_w + half_w;
+            lds[cu_idx(base + d) + r] ^= lds[cu_idx(base + half_w - pw_w + d) + r];
+        }
+    } else {
+        const uint32_t pw = 1u << lpw;
+        const uint32_t items = nchunks * 4;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & 3, c = it >> 2;
+            uint32_t base = c * chunk_w + half_w;
+            lds[cu_idx(base) + r] ^= lds[cu_idx(base + half_w - 1) + r] >> (32 - pw);
+        }
+    }
+}
+
+__device__ __forceinline__ void cu_shift(u4 *lds, uint32_t lchunk, uint32_t lpw) {
+    const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
+    const uint32_t items = 1024 * 4;
+    if (lpw >= 5) {
+        const uint32_t pw_w = 1u << (lpw - 5);
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & 3, wi = it >> 2;
+            uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
+            if (d >= pw_w) {
+                uint32_t base = c * chunk_w;
+                lds[cu_idx(base + d) + r] ^= lds[cu_idx(base + half_w + d - pw_w) + r];
+            }
+        }
+    } else {
+        const uint32_t pw = 1u << lpw;
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            uint32_t r = it & 3, wi = it >> 2;
+            uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
+            uint32_t base = c * chunk_w;
+            u4 h = lds[cu_idx(base + half_w + d) + r] << pw;
+            if (d) h |= lds[cu_idx(base + half_w + d - 1) + r] >> (32 - pw);
+            lds[cu_idx(base + d) + r] ^= h;
+        }
+    }
+}
+
+// masks of one phase for word wd of a 256-bit sub-unit (gf2fft_model.apply_phase)
+constexpr uint32_t rp_m1(int lc, int lp, int wd) {
+    uint32_t m = 0;
+    const int chunk = 1 << lc, pw = 1 << lp, half = chunk >> 1;
+    for (int b = 0; b < 32; b++) {
+        const int l = (32 * wd + b) % chunk;
+        if (l >= half ? (l - half < pw) : (l >= pw)) m |= 1u << b;
+    }
+    return m;
+}
+constexpr uint32_t rp_m2(int lc, int lp, int wd) {
+    uint32_t m = 0;
+    const int chunk = 1 << lc, pw = 1 << lp, half = chunk >> 1;
+    for (int b = 0; b < 32; b++) {
+        const int l = (32 * wd + b) % chunk;
+        if (l < half && l >= pw && l < 2 * pw) m |= 1u << b;
+    }
+    return m;
+}
+template <int BIT>
+__device__ __forceinline__ u4 rp_fetch(const u4 w[8]) {  // bits BIT .. BIT+31 of the 256-bit value, zero beyond
+    constexpr int ws = BIT / 32, sh = BIT % 32;
+    const u4 zero = {0, 0, 0, 0};
+    if (ws >= 8) return zero;
+    u4 lo = w[ws];
+    if (sh == 0) return lo;
+    u4 r = lo >> sh;
+    if (ws + 1 < 8) r |= w[ws + 1] << (32 - sh);
+    return r;
+}
+template <int LC, int LP, bool INV, int WD>
+__device__ __forceinline__ u4 rp_word(const u4 w[8]) {
+    constexpr int D = (1 << (LC - 1)) - (1 << LP);
+    constexpr uint32_t m1 = rp_m1(LC, LP, WD), m2 = INV ? 0u : rp_m2(LC, LP, WD);
+    u4 o = w[WD];
+    if (m1) o ^= rp_fetch<32 * WD + D>(w) & m1;
+    if (m2) o ^= rp_fetch<32 * WD + 2 * D>(w) & m2;
+    return o;
+}
+template <int LC, int LP, bool INV>
+__device__ __forceinline__ void reg_phase(u4 w[8]) {
+    u4 o[8];
+    o[0] = rp_word<LC, LP, INV, 0>(w), o[1] = rp_word<LC, LP, INV, 1>(w), o[2] = rp_word<LC, LP, INV, 2>(w);
+    o[3] = rp_word<LC, LP, INV, 3>(w), o[4] = rp_word<LC, LP, INV, 4>(w), o[5] = rp_word<LC, LP, INV, 5>(w);
+    o[6] = rp_word<LC, LP, INV, 6>(w), o[7] = rp_word<LC, LP, INV, 7>(w);
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = o[j];
+}
+// conversion_phases(8): (8,3) (7,2) (6,1) (5,0) (8,5) (7,4) (8,6) (6,4) (4,1) (3,0) (4,2) (2,0)
+template <bool INV>
+__device__ __forceinline__ void reg_phases(u4 w[8]) {
+    if (!INV) {
+        reg_phase<8, 3, false>(w), reg_phase<7, 2, false>(w), reg_phase<6, 1, false>(w), reg_phase<5, 0, false>(w);
+        reg_phase<8, 5, false>(w), reg_phase<7, 4, false>(w), reg_phase<8, 6, false>(w), reg_phase<6, 4, false>(w);
+        reg_phase<4, 1, false>(w), reg_phase<3, 0, false>(w), reg_phase<4, 2, false>(w), reg_phase<2, 0, false>(w);
+    } else {
+        reg_phase<2, 0, true>(w), reg_phase<4, 2, true>(w), reg_phase<3, 0, true>(w), reg_phase<4, 1, true>(w);
+        reg_phase<6, 4, true>(w), reg_phase<8, 6, true>(w), reg_phase<7, 4, true>(w), reg_phase<8, 5, true>(w);
+        reg_phase<5, 0, true>(w), reg_phase<6, 1, true>(w), reg_phase<7, 2, true>(w), reg_phase<8, 3, true>(w);
+    }
+}
+
+struct move_list {
+    uint32_t nsteps;
+    uint32_t step_end[UP_MAX_STEPS];
+    const uint32_t *list;  // dst | src << 16 (sub-unit indices)
+};
+template <bool INV>
+__global__ void __launch_bounds__(CT_THREADS) k_conv_unit(uint32_t *__restrict__ D, move_list mv) {
+    __shared__ u4 lds[CU_LDS];
+    const uint32_t rowgrp = blockIdx.x & 7;
+    const uint64_t tile = blockIdx.x >> 3;
+    uint32_t *g = D + tile * 2048 * ROWS + rowgrp * CT_ROWS;
+    const uint32_t su = threadIdx.x >> 2, quad = threadIdx.x & 3;  // owner mapping of part P3
+    u4 w[8];
+    if (!INV) {
+        for (uint32_t it = threadIdx.x; it < 2048 * 4; it += CT_THREADS) {
+            uint32_t r = it & 3, wl = it >> 2;
+            lds[cu_idx(wl) + r] = *(const u4 *)(g + (uint64_t)wl * ROWS + 4 * r);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = *(const u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad);
+        reg_phases<true>(w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) lds[36 * su + 4 * j + quad] = w[j];
+    }
+    __syncthreads();
+    // P2 forward comes after P1, inverse before it
+    for (int part = 0; part < 2; part++) {
+        const bool do_p1 = INV ? part == 1 : part == 0;
+        if (do_p1) {
+            for (int q = 0; q < 8; q++) {
+                const uint32_t lpw = INV ? q : 7 - q, lchunk = lpw + 9;
+                if (!INV) {
+                    cu_fold(lds, lchunk, lpw);
+                    __syncthreads();
+                    cu_shift(lds, lchunk, lpw);
+                } else {
+                    cu_shift(lds, lchunk, lpw);
+                    __syncthreads();
+                    cu_fold(lds, lchunk, lpw);
+                }
+                __syncthreads();
+            }
+        } else {
+            const uint32_t x = threadIdx.x & 31, grp = threadIdx.x >> 5;
+            uint32_t start = 0;
+            for (uint32_t st = 0; st < mv.nsteps; st++) {
+                const uint32_t end = mv.step_end[st];
+                for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {
+                    const uint32_t pr = mv.list[it];
+                    lds[36 * (pr & 0xffffu) + x] ^= lds[36 * (pr >> 16) + x];
+                }
+                start = end;
+                __syncthreads();
+            }
+        }
+    }
+    if (!INV) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = lds[36 * su + 4 * j + quad];
+        reg_phases<false>(w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad) = w[j];
+    } else {
+        for (uint32_t it = threadIdx.x; it < 2048 * 4; it += CT_THREADS) {
+            uint32_t r = it & 3, wl = it >> 2;
+            *(u4 *)(g + (uint64_t)wl * ROWS + 4 * r) = lds[cu_idx(wl) + r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2c: the Taylor-expansion phases at y = x^(2^16) + x whose chunk spans several units but whose shift pw is
 // smaller than a unit (gf2fft_model.conversion_phases: chunk = 2^(pb+17), pw = 2^pb), fused in LDS, out of place.
 // Tile = the NU units of one independent group x NC columns (words at the same offsets of every unit) x 4 RQ rows.
@@ -668,7 +863,6 @@ __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, u
 // that are local to a unit, so they run in the same LDS tile as the top butterfly levels (whose word bits are
 // unit-index bits). The host flattens them into a list of (dst slot, src slot) moves grouped in hazard-free steps
 // (fold / shift of each phase); a 16-lane group moves one granule (64 rows x 4 B) per list entry.
-#define UP_MAX_STEPS 64
 struct unit_phases {
     uint32_t nsteps;
     uint32_t step_end[UP_MAX_STEPS];  // list index one past the last move of step s
@@ -1388,7 +1582,8 @@ static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid,
     return true;
 }
 
-static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse, bool units_in_top) {
+static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse, bool units_in_top,
+                          const move_list *sub_fwd, const move_list *sub_inv) {
     const uint64_t nwords = 1ull << (ell_elems - 5);
     std::vector<phase_t> ph;
     conv_rec(ph, ell_elems, 1);
@@ -1438,9 +1633,15 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
             generic(taylor);
         }
         if (!units_in_top) generic(units);
-        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
+        if (fused && tb == 16)
+            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], *sub_fwd);
+        else if (small.n)
+            SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
-        if (small.n) SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
+        if (fused && tb == 16)
+            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], *sub_inv);
+        else if (small.n)
+            SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) generic(units);
         if (fusedT) {
             run_taylor(tB, gB, ncB);
@@ -1497,6 +1698,8 @@ struct fft_plan {
     unit_phases up_fwd, up_inv;  // for an operand (2^(m-1) coefficients) / for the product (2^m)
     unit_phases up_none;
     std::vector<uint32_t> list_fwd, list_inv;  // host copies of the move lists (uploaded once per context)
+    move_list sub_fwd, sub_inv;                // sub-unit moves of k_conv_unit
+    std::vector<uint32_t> sub_list_fwd, sub_list_inv;
     std::vector<tile_desc> w32;  // extra 32-plane word-level passes (m > 25), forward order
 };
 
@@ -1549,6 +1752,31 @@ static fft_plan make_plan(uint32_t m) {
                             }
                     u.step_end[u.nsteps++] = (uint32_t)list.size();
                 }
+            }
+        }
+    }
+    // sub-unit moves of k_conv_unit: conversion of the 256 sub-unit indices of a unit
+    memset(&p.sub_fwd, 0, sizeof p.sub_fwd);
+    memset(&p.sub_inv, 0, sizeof p.sub_inv);
+    for (int inv = 0; inv < 2; inv++) {
+        std::vector<phase_t> ph;
+        conv_rec(ph, 8, 1);
+        std::vector<uint32_t> &list = inv ? p.sub_list_inv : p.sub_list_fwd;
+        move_list &u = inv ? p.sub_inv : p.sub_fwd;
+        for (size_t q = 0; q < ph.size(); q++) {
+            const phase_t &f = inv ? ph[ph.size() - 1 - q] : ph[q];
+            const uint32_t D = (uint32_t)(f.half - f.pw), nchunks = 256u / (uint32_t)f.chunk;
+            for (int step = 0; step < 2; step++) {
+                const bool fold = inv ? step == 1 : step == 0;
+                const uint32_t per = fold ? (uint32_t)f.pw : D;
+                for (uint32_t cidx = 0; cidx < nchunks; cidx++)
+                    for (uint32_t jj = 0; jj < per; jj++) {
+                        const uint32_t base = cidx * (uint32_t)f.chunk;
+                        const uint32_t dst = fold ? base + (uint32_t)f.half + jj : base + (uint32_t)f.pw + jj;
+                        const uint32_t src = fold ? base + (uint32_t)f.half + jj + D : base + (uint32_t)f.half + jj;
+                        list.push_back(dst | (src << 16));
+                    }
+                u.step_end[u.nsteps++] = (uint32_t)list.size();
             }
         }
     }
@@ -1678,7 +1906,7 @@ static int upload_a_and_transform(sot_ctx *c) {
     SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
     hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw / 2, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
     hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * 512, 256)), dim3(256), 0, c->stream, plan.low,
                        g.nw / 32, c->TW, c->LM);
@@ -1733,13 +1961,18 @@ int qc_init(sot_ctx *c) {
     hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
                        13u, 256u, c->TW, c->MT2);
     SOT_HIP(hipGetLastError());
-    if (plan->units_in_top) {
+    {
         const size_t nf = plan->list_fwd.size(), ni = plan->list_inv.size();
-        SOT_TRY(dev_alloc(c, (void **)&c->up_list, (nf + ni + 1) * 4));
-        SOT_HIP(hipMemcpy(c->up_list, plan->list_fwd.data(), nf * 4, hipMemcpyHostToDevice));
-        SOT_HIP(hipMemcpy(c->up_list + nf, plan->list_inv.data(), ni * 4, hipMemcpyHostToDevice));
+        const size_t sf = plan->sub_list_fwd.size(), si = plan->sub_list_inv.size();
+        SOT_TRY(dev_alloc(c, (void **)&c->up_list, (nf + ni + sf + si + 1) * 4));
+        if (nf) SOT_HIP(hipMemcpy(c->up_list, plan->list_fwd.data(), nf * 4, hipMemcpyHostToDevice));
+        if (ni) SOT_HIP(hipMemcpy(c->up_list + nf, plan->list_inv.data(), ni * 4, hipMemcpyHostToDevice));
+        SOT_HIP(hipMemcpy(c->up_list + nf + ni, plan->sub_list_fwd.data(), sf * 4, hipMemcpyHostToDevice));
+        SOT_HIP(hipMemcpy(c->up_list + nf + ni + sf, plan->sub_list_inv.data(), si * 4, hipMemcpyHostToDevice));
         plan->up_fwd.list = c->up_list;
         plan->up_inv.list = c->up_list + nf;
+        plan->sub_fwd.list = c->up_list + nf + ni;
+        plan->sub_inv.list = c->up_list + nf + ni + sf;
     }
     return upload_a_and_transform(c);
 }
@@ -1769,12 +2002,12 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
                g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
     SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), zb[cur], plan.low, c->TW,
                c->LM, c->Amat);
     fft_inverse_upper(c, zb[cur], plan);
-    cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top);
+    cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     if (g.tail > FN_TAILMAX) {
         sot_set_error("internal: tail exceeds FN_TAILMAX");
         return SOT_EINVAL;
@@ -1800,7 +2033,7 @@ int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_ou
     SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
     SOT_HIP(hipMemcpy2DAsync(c->Z0, ROWS * 4, row_in, 4, 4, g.nw / 2, hipMemcpyHostToDevice, c->stream));
     uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false, stage >= 1 && plan.units_in_top);
+    int cur = run_conversion(c, zb, 0, g.m - 1, false, stage >= 1 && plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     uint32_t *Z = zb[cur];
     if (stage >= 1) fft_forward_upper(c, Z, plan, stage);
     if (stage >= 4)
