@@ -264,6 +264,121 @@ def polymul(a, b, m):
     return convert(words_to_int(Zb), m, True)
 
 
+# ---------------------------------------------------------------------------------------------------
+# The same pruned transform in "compact" form for any tower field GF(2^F), F = 8, 16, 32 (positions are
+# renumbered after every pruned level): small enough to test the math exhaustively on the CPU
+# (tests/test_fafft_model.py); checks along the way that tau = 2^r + tau_lo at the pruned levels.
+from gf2fft_model import mono_to_novel, novel_to_mono  # noqa: E402
+
+
+def pruned_levels(F):
+    r = 1
+    out = []
+    while r < F:
+        out.append(r); r *= 2
+    return out  # relative levels r = m - i that are pruned
+
+def small_fft(c, m, F):
+    """c: list of 2^m GF(2) novel-basis coeffs. returns dict-free list of values at cross-section, compact order."""
+    PR = set(pruned_levels(F))
+    # data: list indexed by compact position; keep track of the list of surviving/unprocessed absolute bits
+    data = list(c)
+    bits = list(range(m))  # absolute bit i <-> list index position in compact index (ascending)
+    for i in range(m - 1, -1, -1):
+        r = m - i
+        pos = bits.index(i)  # compact bit position of level i
+        n = len(data)
+        new = None
+        if r in PR:
+            new = [0] * (n // 2)
+        for idx in range(n):
+            if (idx >> pos) & 1:
+                continue
+            # absolute index of higher bits
+            jh = 0
+            for cp, ab in enumerate(bits):
+                if ab > i and (idx >> cp) & 1:
+                    jh |= 1 << ab
+            tau = point(((1 << m) | jh) >> i)
+            x, y = data[idx], data[idx | (1 << pos)]
+            if r in PR:
+                t = r.bit_length() - 1  # r = 2^t
+                assert tau >> r == 1, (hex(tau), r)
+                assert x < (1 << r) and y < (1 << r)
+                v = x ^ nim_mul(tau, y)
+                assert v == (x ^ nim_mul(tau & ((1 << r) - 1), y)) | (y << r)
+                # compact: remove bit pos
+                lo = idx & ((1 << pos) - 1)
+                hi = idx >> (pos + 1)
+                new[(hi << pos) | lo] = v
+            else:
+                x ^= nim_mul(tau, y)
+                y ^= x
+                data[idx], data[idx | (1 << pos)] = x, y
+        if r in PR:
+            data = new
+            bits.remove(i)
+    return data, bits
+
+def small_ifft(vals, m, F):
+    PR = set(pruned_levels(F))
+    bits = [i for i in range(m) if (m - i) not in PR]
+    data = list(vals)
+    for i in range(m):
+        r = m - i
+        if r in PR:
+            # insert bit i into bits
+            pos = sum(1 for b in bits if b < i)
+            n = len(data)
+            new = [0] * (2 * n)
+            newbits = bits[:pos] + [i] + bits[pos:]
+            for idx in range(n):
+                lo = idx & ((1 << pos) - 1)
+                hi = idx >> pos
+                nidx = (hi << (pos + 1)) | lo
+                jh = 0
+                for cp, ab in enumerate(newbits):
+                    if ab > i and (nidx >> cp) & 1:
+                        jh |= 1 << ab
+                tau = point(((1 << m) | jh) >> i)
+                v = data[idx]
+                y = v >> r
+                x = (v & ((1 << r) - 1)) ^ nim_mul(tau & ((1 << r) - 1), y)
+                new[nidx] = x
+                new[nidx | (1 << pos)] = y
+            data = new
+            bits = newbits
+        else:
+            pos = bits.index(i)
+            for idx in range(len(data)):
+                if (idx >> pos) & 1:
+                    continue
+                jh = 0
+                for cp, ab in enumerate(bits):
+                    if ab > i and (idx >> cp) & 1:
+                        jh |= 1 << ab
+                tau = point(((1 << m) | jh) >> i)
+                x, y = data[idx], data[idx | (1 << pos)]
+                y ^= x
+                x ^= nim_mul(tau, y)
+                data[idx], data[idx | (1 << pos)] = x, y
+    return data
+
+def small_polymul(a, b, m, F):
+    n = 1 << m
+    ca = mono_to_novel([(a >> i) & 1 for i in range(n)])
+    cb = mono_to_novel([(b >> i) & 1 for i in range(n)])
+    fa, bits = small_fft(ca, m, F)
+    fb, _ = small_fft(cb, m, F)
+    assert len(fa) == n // F
+    fc = [nim_mul(x, y) for x, y in zip(fa, fb)]
+    cc = small_ifft(fc, m, F)
+    assert all(v in (0, 1) for v in cc), "non-binary coefficients"
+    cm = novel_to_mono(cc)
+    return sum(v << i for i, v in enumerate(cm))
+
+
+
 if __name__ == "__main__":
     import random
     import time
