@@ -32,40 +32,37 @@ __device__ __forceinline__ void aes_lds_fill(uint32_t (*te)[AES_LDS_WORDS]) {
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 
+#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define OR_XOR(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x56)  // (a | b) ^ c
+
 __device__ __forceinline__ blk_t aes_encrypt(const uint32_t (*te)[AES_LDS_WORDS], const uint32_t *__restrict__ rk,
                                              blk_t in) {
     const uint32_t *T = te[0] + (threadIdx.x & 31);
 #define TE(b) T[(b) << 5]
+    // one column of a full round: two 3-input XORs around the three rotations
+#define COL(a, b, c, d, k) XOR3(XOR3(TE((a) & 255), rotl32(TE(((b) >> 8) & 255), 8), rotl32(TE(((c) >> 16) & 255), 16)), \
+                                rotl32(TE((d) >> 24), 24), (k))
     uint32_t s0 = in.x ^ rk[0], s1 = in.y ^ rk[1], s2 = in.z ^ rk[2], s3 = in.w ^ rk[3];
 #pragma unroll
     for (int r = 1; r < 10; r++) {
-        uint32_t t0 = TE(s0 & 255) ^ rotl32(TE((s1 >> 8) & 255), 8) ^ rotl32(TE((s2 >> 16) & 255), 16) ^
-                      rotl32(TE(s3 >> 24), 24) ^ rk[4 * r];
-        uint32_t t1 = TE(s1 & 255) ^ rotl32(TE((s2 >> 8) & 255), 8) ^ rotl32(TE((s3 >> 16) & 255), 16) ^
-                      rotl32(TE(s0 >> 24), 24) ^ rk[4 * r + 1];
-        uint32_t t2 = TE(s2 & 255) ^ rotl32(TE((s3 >> 8) & 255), 8) ^ rotl32(TE((s0 >> 16) & 255), 16) ^
-                      rotl32(TE(s1 >> 24), 24) ^ rk[4 * r + 2];
-        uint32_t t3 = TE(s3 & 255) ^ rotl32(TE((s0 >> 8) & 255), 8) ^ rotl32(TE((s1 >> 16) & 255), 16) ^
-                      rotl32(TE(s2 >> 24), 24) ^ rk[4 * r + 3];
-        s0 = t0;
-        s1 = t1;
-        s2 = t2;
-        s3 = t3;
+        const uint32_t t0 = COL(s0, s1, s2, s3, rk[4 * r]);
+        const uint32_t t1 = COL(s1, s2, s3, s0, rk[4 * r + 1]);
+        const uint32_t t2 = COL(s2, s3, s0, s1, rk[4 * r + 2]);
+        const uint32_t t3 = COL(s3, s0, s1, s2, rk[4 * r + 3]);
+        s0 = t0, s1 = t1, s2 = t2, s3 = t3;
     }
-    // last round: SubBytes + ShiftRows only; TE0 bytes are (2S, S, S, 3S): byte 1 (and 2) hold S[x]
+    // last round: SubBytes + ShiftRows only. TE0 bytes are (2S, S, S, 3S): bytes 1 and 2 hold S[x]; two byte
+    // permutes gather them (v_perm_b32: selector 0-3 = second operand, 4-7 = first operand, 0x0c = zero)
+#define LAST(a, b, c, d, k)                                                                             \
+    OR_XOR(__builtin_amdgcn_perm(TE(((b) >> 8) & 255), TE((a) & 255), 0x0c0c0501u),                     \
+           __builtin_amdgcn_perm(TE((d) >> 24), TE(((c) >> 16) & 255), 0x06020c0cu), (k))
     blk_t o;
-    o.x = (((TE(s0 & 255) >> 8) & 0xffu) | (TE((s1 >> 8) & 255) & 0xff00u) | (TE((s2 >> 16) & 255) & 0xff0000u) |
-           ((TE(s3 >> 24) << 8) & 0xff000000u)) ^
-          rk[40];
-    o.y = (((TE(s1 & 255) >> 8) & 0xffu) | (TE((s2 >> 8) & 255) & 0xff00u) | (TE((s3 >> 16) & 255) & 0xff0000u) |
-           ((TE(s0 >> 24) << 8) & 0xff000000u)) ^
-          rk[41];
-    o.z = (((TE(s2 & 255) >> 8) & 0xffu) | (TE((s3 >> 8) & 255) & 0xff00u) | (TE((s0 >> 16) & 255) & 0xff0000u) |
-           ((TE(s1 >> 24) << 8) & 0xff000000u)) ^
-          rk[42];
-    o.w = (((TE(s3 & 255) >> 8) & 0xffu) | (TE((s0 >> 8) & 255) & 0xff00u) | (TE((s1 >> 16) & 255) & 0xff0000u) |
-           ((TE(s2 >> 24) << 8) & 0xff000000u)) ^
-          rk[43];
+    o.x = LAST(s0, s1, s2, s3, rk[40]);
+    o.y = LAST(s1, s2, s3, s0, rk[41]);
+    o.z = LAST(s2, s3, s0, s1, rk[42]);
+    o.w = LAST(s3, s0, s1, s2, rk[43]);
+#undef LAST
+#undef COL
 #undef TE
     return o;
 }
