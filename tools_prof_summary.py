@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 (rocpd sqlite) outputs of tools_profile.sh into CSV files under profiles/.
+
+  python tools_prof_summary.py gpurun_out/prof_<tag> profiles/<prefix>
+
+Writes <prefix>_kernel_stats.csv (kernel trace: calls, total/avg/min/max ns) and <prefix>_pmc.csv (per kernel,
+per launch averages of every collected counter; FETCH_SIZE additionally x2 as MI355X_MICROARCH.md prescribes
+for gfx950 wide streaming reads; FETCH/WRITE in bytes).
+"""
+import csv
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    m = re.match(r"(?:void )?([A-Za-z_0-9]+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    tr = os.path.join(src, "trace", "trace_results.db")
+    if os.path.exists(tr):
+        c = sqlite3.connect(tr)
+        rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                         "from kernels group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[2] for r in rows)
+        with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0], r[1], r[2], "%.1f" % r[3], "%.2f" % (100.0 * r[2] / tot), r[4], r[5]])
+    pmc = {}
+    for sub in ("fetch", "write", "sq", "sq2"):
+        p = os.path.join(src, sub, sub + "_results.db")
+        if not os.path.exists(p):
+            continue
+        c = sqlite3.connect(p)
+        for name, ctr, n, v, d in c.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) "
+                                            "from counters_collection group by kernel_name, counter_name"):
+            e = pmc.setdefault(short(name), {})
+            e[ctr] = v
+            e["launches"] = n
+            e.setdefault("avg_ns_under_pmc", d)
+    ctrs = sorted({k for e in pmc.values() for k in e} - {"launches", "avg_ns_under_pmc"})
+    with open(prefix + "_pmc.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "avg_ns_under_pmc"] + ctrs + ["fetch_bytes_x2_corrected", "write_bytes"])
+        for k, e in sorted(pmc.items(), key=lambda kv: -kv[1].get("avg_ns_under_pmc", 0) * kv[1]["launches"]):
+            fb = e.get("FETCH_SIZE")
+            wb = e.get("WRITE_SIZE")
+            w.writerow([k, e["launches"], "%.0f" % e["avg_ns_under_pmc"]] + ["%.1f" % e[c] if c in e else "" for c in ctrs]
+                       + ["%.0f" % (fb * 1024 * 2) if fb is not None else "", "%.0f" % (wb * 1024) if wb is not None else ""])
+
+
+if __name__ == "__main__":
+    main()
