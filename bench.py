@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 QC_BYTES_PER_OT = 48.0  # 32 B read (rT) + 16 B write per requested OT
+# AES stage ceiling: 160 T-table lookups (ds_read_b32) per block; a wave64 ds_read_b32 occupies the CU's LDS for
+# 2 cycles (MI355X_MICROARCH.md, LDS table) -> 256 CUs x 2.4 GHz / 2 x 64 lanes / 160 lookups
+AES_PEAK_PER_S = 256 * 2.4e9 / 2 * 64 / 160
+GGM_KERNELS = ("k_roots", "k_ggm_level", "k_ggm_leaf", "k_sender_treegrp", "k_recv_init", "k_recv_fix", "k_recv_last")
 QC_KERNELS = ("k_clear_lsb", "k_qc_load", "k_conv_fwd", "k_conv_fwd_tile", "k_fft_top", "k_fft_mid", "k_fft_low_mul",
               "k_ifft_mid", "k_ifft_top", "k_conv_inv_tile", "k_conv_inv", "k_qc_store", "k_qc_final")
 
@@ -61,6 +65,16 @@ def cpu_baseline(log2n_sample, T):
     }
 
 
+def load_pmc():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
+    the profiler on itself; tools_profile.sh + tools_prof_summary.py produce profiles/pmc_latest.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +83,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="requested OTs per direction = 2^log2n")
     ap.add_argument("--threads", type=int, default=4,
                     help="rayon pool size the reference would use (roots depend on it, pprf.rs:115)")
-    ap.add_argument("--cpu-log2n", type=int, default=22)
+    ap.add_argument("--cpu-log2n", type=int, default=24,
+                    help="CPU baseline sample size (2^24 = the GPU workload itself, about 10-20 s on 16 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
@@ -159,6 +174,27 @@ def main():
                 "basis": "QC-encode stage: 48 B/OT x n per direction / summed device time of the stage's kernels "
                          "per direction (%.3f ms); dominant kernel named" % (qc_ms / 2.0),
             }
+            # every stage against the roofline that bounds it
+            ggm_ms = sum(ms for k, (ms, _) in per_step.items() if k in GGM_KERNELS)
+            aes_ggm = conf.parts * ((2 << conf.depth) - 2) + conf.parts * ((2 << conf.depth) - 4)  # sender + receiver
+            mt_ms = per_step.get("k_mt_bits", (0.0, 0))[0]
+            stages = {
+                "ggm_expand": {"bound": "lds (AES T-table lookups)", "ms_per_step": ggm_ms,
+                               "achieved": aes_ggm / (ggm_ms * 1e-3) if ggm_ms else None, "peak": AES_PEAK_PER_S,
+                               "unit": "AES blocks/s"},
+                "qc_encode": {"bound": "hbm", "ms_per_step": qc_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s (48 B/OT algorithmic)"},
+                "hash_mt_bits": {"bound": "lds (AES T-table lookups)", "ms_per_step": mt_ms,
+                                 "achieved": 3.0 * n / (mt_ms * 1e-3) if mt_ms else None, "peak": AES_PEAK_PER_S,
+                                 "unit": "AES blocks/s"},
+            }
+            for st in stages.values():
+                st["frac"] = st["achieved"] / st["peak"] if st["achieved"] else None
+            out["stages"] = stages
+            pmc = load_pmc()
+            if pmc:
+                out["roofline"]["traffic"] = pmc.get("dominant_traffic_bytes_per_launch")
+                out["roofline"]["traffic_note"] = pmc.get("note")
             out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(),
                                                                                 key=lambda kv: -kv[1][0])}
         if not args.no_cpu_baseline:

@@ -11,7 +11,8 @@
 #include "sot_internal.h"
 #include <string.h>
 
-#define GGM_BLOCK 256
+#define GGM_BLOCK 512  // 8 waves; the 64 KiB AES table allows two workgroups per CU
+#define HASH_BLOCK 512
 
 // ------------------------------------------------------------------------------------------------
 // roots: worker t = set % T owns AesRng(seed ^ t); its i-th group (i = set / T) takes keystream blocks
@@ -24,15 +25,15 @@ __global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t p
     uint32_t set = tr >> 3, j = tr & 7;
     uint32_t t = set % T, i = set / T;
     blk_t ctr = make_uint4(8 * i + j, 0, 0, 0);
-    out[tr] = aes_encrypt(te, rks + 44 * t, ctr);
+    out[tr] = aes_encrypt(te, rks + AES_RK_WORDS * t, ctr);
 }
 
 // generic-key CTR keystream: out[i] = AES_rk(LE128(first + i))   (util/aes_rng.rs:109-122)
 __global__ void k_aes_ctr(const uint32_t *__restrict__ rk, uint64_t first, blk_t *__restrict__ out, uint64_t n) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
-    __shared__ uint32_t srk[44];
+    __shared__ uint32_t srk[AES_RK_WORDS];
     aes_lds_fill(te);
-    if (threadIdx.x < 44) srk[threadIdx.x] = rk[threadIdx.x];
+    if (threadIdx.x < AES_RK_WORDS) srk[threadIdx.x] = rk[threadIdx.x];
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t c = first + i;
@@ -44,9 +45,9 @@ __global__ void k_aes_ctr(const uint32_t *__restrict__ rk, uint64_t first, blk_t
 __global__ void k_aes_ecb(const uint32_t *__restrict__ rk, const blk_t *__restrict__ in, blk_t *__restrict__ out,
                           uint64_t n, int mode) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
-    __shared__ uint32_t srk[44];
+    __shared__ uint32_t srk[AES_RK_WORDS];
     aes_lds_fill(te);
-    if (threadIdx.x < 44) srk[threadIdx.x] = mode ? c_rk_fixed[AES_KH][threadIdx.x] : rk[threadIdx.x];
+    if (threadIdx.x < AES_RK_WORDS) srk[threadIdx.x] = mode ? c_rk_fixed[AES_KH][threadIdx.x] : rk[threadIdx.x];
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         blk_t x = in[i];
@@ -330,6 +331,7 @@ void aes_expand_key_host(const uint8_t key[16], aes_rk *out) {
         for (int k = 0; k < 4; k++) rk[4 * i + k] = rk[4 * (i - 4) + k] ^ t[k];
     }
     memcpy(out->w, rk, 176);
+    for (int i = 0; i < 44; i++) out->w[44 + i] = (out->w[i] >> 8) | (out->w[i] << 24);
 }
 
 static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 4096) {
@@ -496,7 +498,7 @@ int hash_sender(sot_ctx *c, const void *delta, void *msgs_out) {
     SOT_TRY(ensure_tmp(c, cf.n * 32));
     blk_t d;
     memcpy(&d, delta, 16);
-    SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256),
+    SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
                        c->role[SOT_ROLE_SENDER].enc, d, cf.n, (blk_t *)c->d_tmp);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 32, hipMemcpyDeviceToHost, c->stream));
@@ -513,7 +515,7 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
     SOT_HIP(hipSetDevice(c->device));
     SOT_TRY(ensure_tmp(c, cf.n * 32));
     uint64_t nw = (cf.n + 63) / 64;
-    SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(cf.n, 256, 2048)), dim3(256),
+    SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
                        c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_mt);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -532,7 +534,7 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
     uint64_t nw = (cf.n + 63) / 64;
     blk_t d;
     memcpy(&d, delta, 16);
-    SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(cf.n, 256, 2048)), dim3(256), c->role[0].enc,
+    SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[0].enc,
                        c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
     SOT_HIP(hipGetLastError());
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));

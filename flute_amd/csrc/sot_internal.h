@@ -27,9 +27,9 @@ void sot_set_error(const char *fmt, ...);
         if (_rc != SOT_OK) return _rc; \
     } while (0)
 
-// AES-128 expanded key: 44 little-endian words
+// AES-128 expanded key: 44 little-endian words, then the same words rotated right by 8 bits (aes_dev.h)
 struct aes_rk {
-    uint32_t w[44];
+    uint32_t w[88];
 };
 void aes_expand_key_host(const uint8_t key[16], aes_rk *out);
 
@@ -98,7 +98,7 @@ struct sot_ctx {
     blk_t *d_base = nullptr;                   // base OTs (sender: pairs)
     uint8_t *d_choices = nullptr;
     blk_t *d_tg_sums = nullptr, *d_tg_last = nullptr;
-    uint32_t *d_rks = nullptr;  // root PRG round keys, [T][44]
+    uint32_t *d_rks = nullptr;  // root PRG round keys, [T][88]
     uint64_t rks_cap = 0;
     // QC scratch
     uint32_t *Z0 = nullptr, *Z1 = nullptr;  // bit rows [word][128 rows], ping-pong (the transform runs in place)

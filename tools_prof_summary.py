@@ -55,5 +55,22 @@ def main():
                        + ["%.0f" % (fb * 1024 * 2) if fb is not None else "", "%.0f" % (wb * 1024) if wb is not None else ""])
 
 
+    # profiles/pmc_latest.json: what bench.py reports as roofline.traffic (dominant kernel, per launch)
+    dom = "k_fft_low<1>"
+    if dom in pmc and "FETCH_SIZE" in pmc[dom] and "WRITE_SIZE" in pmc[dom]:
+        import json
+        e = pmc[dom]
+        out = {
+            "kernel": dom, "source": os.path.basename(prefix) + "_pmc.csv",
+            "fetch_size_kib_raw": e["FETCH_SIZE"], "write_size_kib": e["WRITE_SIZE"],
+            "dominant_traffic_bytes_per_launch": e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024,
+            "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 tallies 128-B "
+                    "requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch of " + dom + "; an upper "
+                    "bound: the kernel also streams its mask tables through 64-B scalar loads, which the x2 over-corrects",
+        }
+        with open(os.path.join(os.path.dirname(prefix), "pmc_latest.json"), "w") as f:
+            json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     main()
