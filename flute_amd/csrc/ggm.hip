@@ -60,6 +60,27 @@ __global__ void k_aes_ecb(const uint32_t *__restrict__ rk, const blk_t *__restri
 // one GGM level for every tree: child[2j+k] = AES_{k_k}(parent[j]) ^ parent[j], per-level XOR sums
 // (pprf.rs:141-194 sender, :388-450 receiver). blockIdx.y = set.
 template <bool LAST>
+__device__ __forceinline__ void ggm_put(blk_t *__restrict__ out, uint32_t set, uint64_t per_set, uint32_t nsets,
+                                        uint64_t cols, uint64_t idx, blk_t c0, blk_t c1) {
+    const uint64_t node = idx >> 3;
+    const uint32_t t8 = idx & 7;
+    if (!LAST) {
+        blk_t *pout = out + (uint64_t)set * per_set * 2;
+        pout[(2 * node) * 8 + t8] = c0;
+        pout[(2 * node + 1) * 8 + t8] = c1;
+    } else {
+        // leaves 2*node, 2*node+1 live in the same 16-leaf tile
+        const uint64_t leaf = 2 * node;
+        const uint64_t tile = set + (uint64_t)nsets * (leaf >> 4);
+        if (tile < cols) {
+            blk_t *pv = out + tile * 128 + 8 * (leaf & 15) + t8;
+            pv[0] = c0;
+            pv[8] = c1;
+        }
+    }
+}
+
+template <bool LAST>
 __global__ void __launch_bounds__(GGM_BLOCK)
     k_ggm_level(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t lvl, uint32_t nsets, uint64_t cols,
                 blk_t *__restrict__ sums /* this level: [set][2][8] */) {
@@ -70,28 +91,29 @@ __global__ void __launch_bounds__(GGM_BLOCK)
     const uint64_t per_set = (uint64_t)8 << lvl;  // parent Blocks of this set
     const blk_t *pin = in + (uint64_t)set * per_set;
     blk_t acc0 = bzero(), acc1 = bzero();
-    for (uint64_t idx = (uint64_t)blockIdx.x * GGM_BLOCK + threadIdx.x; idx < per_set;
-         idx += (uint64_t)gridDim.x * GGM_BLOCK) {
-        blk_t p = pin[idx];
-        blk_t c0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], p), p);
-        blk_t c1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], p), p);
-        acc0 = bxor(acc0, c0);
-        acc1 = bxor(acc1, c1);
-        uint64_t node = idx >> 3;
-        uint32_t t8 = idx & 7;
-        if (!LAST) {
-            blk_t *pout = out + (uint64_t)set * per_set * 2;
-            pout[(2 * node) * 8 + t8] = c0;
-            pout[(2 * node + 1) * 8 + t8] = c1;
-        } else {
-            // leaves 2*node, 2*node+1 live in the same 16-leaf tile
-            uint64_t leaf = 2 * node;
-            uint64_t tile = set + (uint64_t)nsets * (leaf >> 4);
-            if (tile < cols) {
-                blk_t *pv = out + tile * 128 + 8 * (leaf & 15) + t8;
-                pv[0] = c0;
-                pv[8] = c1;
-            }
+    const uint64_t stride = (uint64_t)gridDim.x * GGM_BLOCK;  // a multiple of 8: a thread keeps its tree%8
+    if (per_set % (2 * stride) == 0) {
+        // two parents (four independent AES chains) per iteration: the T-table lookups are latency bound otherwise
+        for (uint64_t idx = (uint64_t)blockIdx.x * GGM_BLOCK + threadIdx.x; idx < per_set; idx += 2 * stride) {
+            const uint64_t idx2 = idx + stride;
+            blk_t p = pin[idx], q = pin[idx2];
+            blk_t c0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], p), p);
+            blk_t c1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], p), p);
+            blk_t e0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], q), q);
+            blk_t e1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], q), q);
+            acc0 = bxor(acc0, bxor(c0, e0));
+            acc1 = bxor(acc1, bxor(c1, e1));
+            ggm_put<LAST>(out, set, per_set, nsets, cols, idx, c0, c1);
+            ggm_put<LAST>(out, set, per_set, nsets, cols, idx2, e0, e1);
+        }
+    } else {
+        for (uint64_t idx = (uint64_t)blockIdx.x * GGM_BLOCK + threadIdx.x; idx < per_set; idx += stride) {
+            blk_t p = pin[idx];
+            blk_t c0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], p), p);
+            blk_t c1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], p), p);
+            acc0 = bxor(acc0, c0);
+            acc1 = bxor(acc1, c1);
+            ggm_put<LAST>(out, set, per_set, nsets, cols, idx, c0, c1);
         }
     }
     // XOR-reduce over lanes with equal tree%8 (lane bits 3..5), then over the block's waves

@@ -955,6 +955,14 @@ __device__ __forceinline__ void apply_masks(uint32_t acc[32], const uint32_t v[N
     }
 }
 
+// touch the 64-B line at a (one line per lane) with a vector load whose result is never used. The loads are invisible to
+// the compiler's vmcnt bookkeeping: only issue them where no compiler-generated global load is in flight, keep
+// `pf` (the one destination register) alive, and drain before anything else uses vector memory.
+__device__ __forceinline__ void mask_prefetch(uint32_t &pf, const uint32_t *a) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void mask_prefetch_drain(uint32_t &pf) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf)::"memory"); }
+
 template <int I, bool INV>
 __device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
     const uint32_t A = lowmask(I);
@@ -1277,38 +1285,58 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t rh = blockIdx.x & 1;
     const uint32_t o = blockIdx.x >> 1;
     const uint32_t base_w = tile_base(d, o);
+#ifndef QC_EXP
+#define QC_EXP 0  // profiling experiments only (tools_exp.sh): 1 = no word levels, 2 = no intra-word levels
+#endif
+    const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
+    // first mask lines of this wave's value word (see mask_prefetch); issued before the tile's own loads, so they
+    // are older than every load the compiler tracks
+    uint32_t pf = 0;
+    if (wave < nvw) mask_prefetch(pf, LM + ((uint64_t)o * nvw + wave) * (5 * 512) + 3 * 512 + lane * 16);  // levels 3, 4
     tile_load<9>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
-    low_word_levels<false>(lds, d, base_w, TW, wave, lane);
-    const uint32_t nvw = 1u << (d.nb - 5);  // value words in the tile
+    if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
     for (uint32_t vi = wave; vi < nvw; vi += TL_WAVES) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
         const uint64_t vw = (uint64_t)o * nvw + vi;  // wave-uniform
         const uint32_t *L = LM + vw * (5 * 512);
+        const uint32_t *A = Amat + vw * 1024;
+        // The 14 KiB of masks of this value word are streamed once through the scalar unit, two 128-B rows in
+        // flight: far too little to cover an HBM miss. Vector loads that touch the lines ahead of time (one lane
+        // per 64-B line, result unused) pull them into L2 one to two levels before the scalar loads arrive.
+        const uint32_t l16 = lane * 16, h16 = (lane & 31) * 16;
+        if (vi != wave) mask_prefetch(pf, L + 3 * 512 + l16);  // levels 3, 4
         uint32_t W[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
+        mask_prefetch(pf, L + 1 * 512 + l16);  // levels 1, 2
         low_level<4, false>(W, L + 4 * 512);
         low_level<3, false>(W, L + 3 * 512);
+        mask_prefetch(pf, (lane < 32 || MODE == 0 ? L : A) + h16);  // level 0 | first half of Amat
         low_level<2, false>(W, L + 2 * 512);
+        if (MODE == 1) mask_prefetch(pf, A + 512 + h16);  // second half of Amat
         low_level<1, false>(W, L + 1 * 512);
         low_level<0, false>(W, L);
         if (MODE == 1) {
             uint32_t t[32];
-            apply_masks<32>(t, W, Amat + vw * 1024);  // Amat[value word][j][k]
+            mask_prefetch(pf, L + l16);  // levels 0, 1 again (the inverse levels)
+            apply_masks<32>(t, W, A);    // Amat[value word][j][k]
 #pragma unroll
             for (int k = 0; k < 32; k++) W[k] = t[k];
+            mask_prefetch(pf, L + 2 * 512 + l16);  // levels 2, 3
             low_level<0, true>(W, L);
             low_level<1, true>(W, L + 1 * 512);
+            mask_prefetch(pf, L + 4 * 512 + h16);  // level 4
             low_level<2, true>(W, L + 2 * 512);
             low_level<3, true>(W, L + 3 * 512);
             low_level<4, true>(W, L + 4 * 512);
         }
+        mask_prefetch_drain(pf);
 #pragma unroll
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
     }
     __syncthreads();
-    if (MODE == 1) low_word_levels<true>(lds, d, base_w, TW, wave, lane);
+    if (MODE == 1 && !(QC_EXP & 1)) low_word_levels<true>(lds, d, base_w, TW, wave, lane);
     tile_store<9>(lds, Z, d, base_w, rh, wave, lane);
 }
 
