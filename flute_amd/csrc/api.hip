@@ -208,6 +208,7 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
     }
     sot_ctx *c = new sot_ctx();
     c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     int rc = sot_configure(n, scaler, 128, &c->conf);
     if (rc != SOT_OK) {
         delete c;

@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(CT_THREADS)
 // 128-bit accesses of a quarter wave on distinct banks when threads own sub-units.
 #define UP_MAX_STEPS 64
 #define CU_LDS (2048 * 4 + 256 * 4)
+#define CU_MAX_MOVES 1536  // 12 sub-unit phases x at most 128 moves
 __device__ __forceinline__ uint32_t cu_idx(uint32_t word) { return (word << 2) + ((word >> 3) << 2); }
 
 __device__ __forceinline__ void cu_fold(u4 *lds, uint32_t lchunk, uint32_t lpw) {
@@ -434,46 +435,48 @@ constexpr uint32_t rp_m2(int lc, int lp, int wd) {
     }
     return m;
 }
-template <int BIT>
-__device__ __forceinline__ u4 rp_fetch(const u4 w[8]) {  // bits BIT .. BIT+31 of the 256-bit value, zero beyond
+// T = u4 (four rows at once) or uint32_t (one row: a quarter of the registers)
+template <int BIT, class T>
+__device__ __forceinline__ T rp_fetch(const T w[8]) {  // bits BIT .. BIT+31 of the 256-bit value, zero beyond
     constexpr int ws = BIT / 32, sh = BIT % 32;
-    const u4 zero = {0, 0, 0, 0};
-    if (ws >= 8) return zero;
-    u4 lo = w[ws];
+    if (ws >= 8) return T{};
+    T lo = w[ws];
     if (sh == 0) return lo;
-    u4 r = lo >> sh;
+    T r = lo >> sh;
     if (ws + 1 < 8) r |= w[ws + 1] << (32 - sh);
     return r;
 }
-template <int LC, int LP, bool INV, int WD>
-__device__ __forceinline__ u4 rp_word(const u4 w[8]) {
+template <int LC, int LP, bool INV, int WD, class T>
+__device__ __forceinline__ T rp_word(const T w[8]) {
     constexpr int D = (1 << (LC - 1)) - (1 << LP);
     constexpr uint32_t m1 = rp_m1(LC, LP, WD), m2 = INV ? 0u : rp_m2(LC, LP, WD);
-    u4 o = w[WD];
-    if (m1) o ^= rp_fetch<32 * WD + D>(w) & m1;
-    if (m2) o ^= rp_fetch<32 * WD + 2 * D>(w) & m2;
+    T o = w[WD];
+    if (m1) o ^= rp_fetch<32 * WD + D, T>(w) & m1;
+    if (m2) o ^= rp_fetch<32 * WD + 2 * D, T>(w) & m2;
     return o;
 }
-template <int LC, int LP, bool INV>
-__device__ __forceinline__ void reg_phase(u4 w[8]) {
-    u4 o[8];
-    o[0] = rp_word<LC, LP, INV, 0>(w), o[1] = rp_word<LC, LP, INV, 1>(w), o[2] = rp_word<LC, LP, INV, 2>(w);
-    o[3] = rp_word<LC, LP, INV, 3>(w), o[4] = rp_word<LC, LP, INV, 4>(w), o[5] = rp_word<LC, LP, INV, 5>(w);
-    o[6] = rp_word<LC, LP, INV, 6>(w), o[7] = rp_word<LC, LP, INV, 7>(w);
+template <int LC, int LP, bool INV, class T>
+__device__ __forceinline__ void reg_phase(T w[8]) {
+    T o[8];
+    o[0] = rp_word<LC, LP, INV, 0, T>(w), o[1] = rp_word<LC, LP, INV, 1, T>(w), o[2] = rp_word<LC, LP, INV, 2, T>(w);
+    o[3] = rp_word<LC, LP, INV, 3, T>(w), o[4] = rp_word<LC, LP, INV, 4, T>(w), o[5] = rp_word<LC, LP, INV, 5, T>(w);
+    o[6] = rp_word<LC, LP, INV, 6, T>(w), o[7] = rp_word<LC, LP, INV, 7, T>(w);
 #pragma unroll
     for (int j = 0; j < 8; j++) w[j] = o[j];
 }
 // conversion_phases(8): (8,3) (7,2) (6,1) (5,0) (8,5) (7,4) (8,6) (6,4) (4,1) (3,0) (4,2) (2,0)
-template <bool INV>
-__device__ __forceinline__ void reg_phases(u4 w[8]) {
+template <bool INV, class T>
+__device__ __forceinline__ void reg_phases(T w[8]) {
     if (!INV) {
-        reg_phase<8, 3, false>(w), reg_phase<7, 2, false>(w), reg_phase<6, 1, false>(w), reg_phase<5, 0, false>(w);
-        reg_phase<8, 5, false>(w), reg_phase<7, 4, false>(w), reg_phase<8, 6, false>(w), reg_phase<6, 4, false>(w);
-        reg_phase<4, 1, false>(w), reg_phase<3, 0, false>(w), reg_phase<4, 2, false>(w), reg_phase<2, 0, false>(w);
+        reg_phase<8, 3, false, T>(w), reg_phase<7, 2, false, T>(w), reg_phase<6, 1, false, T>(w);
+        reg_phase<5, 0, false, T>(w), reg_phase<8, 5, false, T>(w), reg_phase<7, 4, false, T>(w);
+        reg_phase<8, 6, false, T>(w), reg_phase<6, 4, false, T>(w), reg_phase<4, 1, false, T>(w);
+        reg_phase<3, 0, false, T>(w), reg_phase<4, 2, false, T>(w), reg_phase<2, 0, false, T>(w);
     } else {
-        reg_phase<2, 0, true>(w), reg_phase<4, 2, true>(w), reg_phase<3, 0, true>(w), reg_phase<4, 1, true>(w);
-        reg_phase<6, 4, true>(w), reg_phase<8, 6, true>(w), reg_phase<7, 4, true>(w), reg_phase<8, 5, true>(w);
-        reg_phase<5, 0, true>(w), reg_phase<6, 1, true>(w), reg_phase<7, 2, true>(w), reg_phase<8, 3, true>(w);
+        reg_phase<2, 0, true, T>(w), reg_phase<4, 2, true, T>(w), reg_phase<3, 0, true, T>(w);
+        reg_phase<4, 1, true, T>(w), reg_phase<6, 4, true, T>(w), reg_phase<8, 6, true, T>(w);
+        reg_phase<7, 4, true, T>(w), reg_phase<8, 5, true, T>(w), reg_phase<5, 0, true, T>(w);
+        reg_phase<6, 1, true, T>(w), reg_phase<7, 2, true, T>(w), reg_phase<8, 3, true, T>(w);
     }
 }
 
@@ -482,69 +485,125 @@ struct move_list {
     uint32_t step_end[UP_MAX_STEPS];
     const uint32_t *list;  // dst | src << 16 (sub-unit indices)
 };
+// INV: thread owns sub-unit su (8 consecutive words) x row quad; forward: words su, su + 256, ...
+// (eight named registers, not an array: as a loop-carried array the prefetched tile ends up in scratch memory)
+// a 16-byte load as values (a plain u4 struct copy is a memcpy that can pin its destination in scratch memory)
+__device__ __forceinline__ u4 ld_u4(const uint32_t *p) {
+    const uint4 t = *(const uint4 *)p;
+    return {t.x, t.y, t.z, t.w};
+}
+struct cu_regs {
+    u4 a, b, c, d, e, f, g, h;
+};
 template <bool INV>
-__global__ void __launch_bounds__(CT_THREADS) k_conv_unit(uint32_t *__restrict__ D, move_list mv) {
+__device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, uint32_t quad) {
+    const uint32_t *p = g + (uint64_t)(INV ? 8 * su : su) * ROWS + 4 * quad;
+    constexpr uint64_t st = (INV ? 1 : 256) * ROWS;
+    cu_regs r;
+    r.a = ld_u4(p), r.b = ld_u4(p + st), r.c = ld_u4(p + 2 * st), r.d = ld_u4(p + 3 * st);
+    r.e = ld_u4(p + 4 * st), r.f = ld_u4(p + 5 * st), r.g = ld_u4(p + 6 * st), r.h = ld_u4(p + 7 * st);
+    return r;
+}
+
+// Persistent: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the tile fills all of the
+// CU's LDS, so the only way to overlap HBM with the LDS phases is in time: the next tile's 32 registers per thread
+// are loaded while the current tile is being processed.
+template <bool INV>
+__global__ void __launch_bounds__(CT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8) {
     __shared__ u4 lds[CU_LDS];
-    const uint32_t rowgrp = blockIdx.x & 7;
-    const uint64_t tile = blockIdx.x >> 3;
-    uint32_t *g = D + tile * 2048 * ROWS + rowgrp * CT_ROWS;
+    __shared__ uint32_t mvl[CU_MAX_MOVES];  // the move list, staged once (a global load in P2 would drain the prefetch)
     const uint32_t su = threadIdx.x >> 2, quad = threadIdx.x & 3;  // owner mapping of part P3
-    u4 w[8];
-    if (!INV) {
-        for (uint32_t it = threadIdx.x; it < 2048 * 4; it += CT_THREADS) {
-            uint32_t r = it & 3, wl = it >> 2;
-            lds[cu_idx(wl) + r] = *(const u4 *)(g + (uint64_t)wl * ROWS + 4 * r);
-        }
-    } else {
+    // INV: thread owns sub-unit su (8 words) x row quad; forward load: word wl = it >> 2 of pass i
+    auto gptr = [&](uint32_t t) { return D + (uint64_t)(t >> 3) * 2048 * ROWS + (t & 7) * CT_ROWS; };
+    uint32_t t = blockIdx.x;
+    if (t >= ntiles8) return;
+    for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += CT_THREADS) mvl[i] = mv.list[i];
+    cu_regs nx = cu_load_tile<INV>(gptr(t), su, quad);
+    for (; t < ntiles8; t += gridDim.x) {
+        uint32_t *g = gptr(t);
+        {
+            u4 w[8] = {nx.a, nx.b, nx.c, nx.d, nx.e, nx.f, nx.g, nx.h};
+            if (!INV) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) w[j] = *(const u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad);
-        reg_phases<true>(w);
+                for (int j = 0; j < 8; j++) lds[cu_idx(su + 256 * j) + quad] = w[j];
+            } else {
+                reg_phases<true, u4>(w);
 #pragma unroll
-        for (int j = 0; j < 8; j++) lds[36 * su + 4 * j + quad] = w[j];
-    }
-    __syncthreads();
-    // P2 forward comes after P1, inverse before it
-    for (int part = 0; part < 2; part++) {
-        const bool do_p1 = INV ? part == 1 : part == 0;
-        if (do_p1) {
-            for (int q = 0; q < 8; q++) {
-                const uint32_t lpw = INV ? q : 7 - q, lchunk = lpw + 9;
-                if (!INV) {
-                    cu_fold(lds, lchunk, lpw);
-                    __syncthreads();
-                    cu_shift(lds, lchunk, lpw);
-                } else {
-                    cu_shift(lds, lchunk, lpw);
-                    __syncthreads();
-                    cu_fold(lds, lchunk, lpw);
-                }
-                __syncthreads();
+                for (int j = 0; j < 8; j++) lds[36 * su + 4 * j + quad] = w[j];
             }
+        }
+        __syncthreads();
+        {  // next tile: in flight during the LDS phases (the last iteration re-reads its own tile: unconditional
+           // loads keep w[] in registers)
+            nx = cu_load_tile<INV>(gptr(t + gridDim.x < ntiles8 ? t + gridDim.x : t), su, quad);
+        }
+        // P2 forward comes after P1, inverse before it
+        for (int part = 0; part < 2; part++) {
+            const bool do_p1 = INV ? part == 1 : part == 0;
+            if (do_p1) {
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t lpw = INV ? q : 7 - q, lchunk = lpw + 9;
+                    if (!INV) {
+                        cu_fold(lds, lchunk, lpw);
+                        __syncthreads();
+                        cu_shift(lds, lchunk, lpw);
+                    } else {
+                        cu_shift(lds, lchunk, lpw);
+                        __syncthreads();
+                        cu_fold(lds, lchunk, lpw);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                const uint32_t x = threadIdx.x & 31, grp = threadIdx.x >> 5;
+                uint32_t start = 0;
+                for (uint32_t st = 0; st < mv.nsteps; st++) {
+                    const uint32_t end = mv.step_end[st];
+                    for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {
+                        const uint32_t pr = mvl[it];
+                        lds[36 * (pr & 0xffffu) + x] ^= lds[36 * (pr >> 16) + x];
+                    }
+                    start = end;
+                    __syncthreads();
+                }
+            }
+        }
+        if (!INV) {
+            u4 o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = lds[36 * su + 4 * j + quad];
+            // one row at a time: the prefetched tile already holds 32 registers
+            {
+                uint32_t x[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = o[j].x;
+                reg_phases<false, uint32_t>(x);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j].x = x[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = o[j].y;
+                reg_phases<false, uint32_t>(x);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j].y = x[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = o[j].z;
+                reg_phases<false, uint32_t>(x);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j].z = x[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = o[j].w;
+                reg_phases<false, uint32_t>(x);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j].w = x[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad) = o[j];
         } else {
-            const uint32_t x = threadIdx.x & 31, grp = threadIdx.x >> 5;
-            uint32_t start = 0;
-            for (uint32_t st = 0; st < mv.nsteps; st++) {
-                const uint32_t end = mv.step_end[st];
-                for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {
-                    const uint32_t pr = mv.list[it];
-                    lds[36 * (pr & 0xffffu) + x] ^= lds[36 * (pr >> 16) + x];
-                }
-                start = end;
-                __syncthreads();
-            }
-        }
-    }
-    if (!INV) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) w[j] = lds[36 * su + 4 * j + quad];
-        reg_phases<false>(w);
-#pragma unroll
-        for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad) = w[j];
-    } else {
-        for (uint32_t it = threadIdx.x; it < 2048 * 4; it += CT_THREADS) {
-            uint32_t r = it & 3, wl = it >> 2;
-            *(u4 *)(g + (uint64_t)wl * ROWS + 4 * r) = lds[cu_idx(wl) + r];
+            for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(su + 256 * j) * ROWS + 4 * quad) = lds[cu_idx(su + 256 * j) + quad];
         }
+        __syncthreads();  // the tile's LDS is free again
     }
 }
 
@@ -1662,12 +1721,12 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
         if (!units_in_top) generic(units);
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], *sub_fwd);
+            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_fwd, tgrid);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], *sub_inv);
+            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_inv, tgrid);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) generic(units);
@@ -1807,6 +1866,7 @@ static fft_plan make_plan(uint32_t m) {
                 u.step_end[u.nsteps++] = (uint32_t)list.size();
             }
         }
+        if (list.size() > CU_MAX_MOVES || u.nsteps == 0) abort();  // a constant of the algorithm, not of the input
     }
     // 16-plane passes (k_mid): tile bits = 4 plane bits, then the 4 level bits in level order
     p.mid1 = make_desc(m, {1, 2, 4, 8}, {9, 10, 11, 12});

@@ -86,6 +86,7 @@ struct role_state {
 
 struct sot_ctx {
     int device = 0;
+    uint32_t num_cus = 256;  // persistent kernels launch one workgroup per CU
     hipStream_t stream = nullptr;
     sot_conf conf;
     qc_geom g;
