@@ -520,6 +520,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8) {
     if (t >= ntiles8) return;
     for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += CT_THREADS) mvl[i] = mv.list[i];
     cu_regs nx = cu_load_tile<INV>(gptr(t), su, quad);
+#pragma unroll 1
     for (; t < ntiles8; t += gridDim.x) {
         uint32_t *g = gptr(t);
         {
@@ -811,6 +812,40 @@ __device__ __forceinline__ void tile_load(uint32_t *lds, const uint32_t *__restr
         if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
     }
 }
+// the same in two steps, for the persistent kernels that fetch the next tile while they work on the current one.
+// The granules travel in one vector value (a loop-carried private ARRAY ends up in scratch memory).
+template <int N>
+struct tile_regs {
+    typedef uint32_t type __attribute__((ext_vector_type(N)));
+};
+template <int NB>
+__device__ __forceinline__ typename tile_regs<(1 << NB) / TL_WAVES>::type tile_fetch(
+    const uint32_t *__restrict__ Z, const tile_desc &d, uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
+    constexpr int PER = (1 << NB) / TL_WAVES;
+    const uint32_t nslots = 1u << d.nb;
+    const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+    typename tile_regs<PER>::type v;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t s = wave + TL_WAVES * i;
+        uint32_t x = 0;
+        if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u)))
+            x = g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS];
+        v[i] = x;
+    }
+    return v;
+}
+template <int NB>
+__device__ __forceinline__ void tile_put(uint32_t *lds, typename tile_regs<(1 << NB) / TL_WAVES>::type v,
+                                         const tile_desc &d, uint32_t wave, uint32_t lane) {
+    constexpr int PER = (1 << NB) / TL_WAVES;
+    const uint32_t nslots = 1u << d.nb;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint32_t s = wave + TL_WAVES * i;
+        if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
+    }
+}
 template <int NB>
 __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__restrict__ Z, const tile_desc &d,
                                            uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
@@ -928,14 +963,14 @@ struct unit_phases {
     const uint32_t *list;             // device memory: dst | src << 16
 };
 
-__device__ __forceinline__ void tile_unit_phases(uint32_t *lds, const unit_phases &up) {
+__device__ __forceinline__ void tile_unit_phases(uint32_t *lds, const unit_phases &up, const uint32_t *list) {
     u4 *l4 = (u4 *)lds;
     const uint32_t rq = threadIdx.x & 15, g = threadIdx.x >> 4;
     uint32_t start = 0;
     for (uint32_t st = 0; st < up.nsteps; st++) {
         const uint32_t end = up.step_end[st];
         for (uint32_t it = start + g; it < end; it += TL_THREADS / 16) {
-            const uint32_t pr = up.list[it];
+            const uint32_t pr = list[it];
             l4[(pr & 0xffffu) * 16 + rq] ^= l4[(pr >> 16) * 16 + rq];
         }
         start = end;
@@ -954,9 +989,9 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
     tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
-    if (!INV && up.nsteps) tile_unit_phases(lds, up);
+    if (!INV && up.nsteps) tile_unit_phases(lds, up, up.list);
     tile_levels<INV>(lds, d, base_w, TW, wave, lane);
-    if (INV && up.nsteps) tile_unit_phases(lds, up);
+    if (INV && up.nsteps) tile_unit_phases(lds, up, up.list);
     tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
 }
 
@@ -1137,20 +1172,38 @@ __device__ __forceinline__ void top_levels(uint32_t *lds, uint32_t nb, const uin
     }
 }
 
+// Persistent (one workgroup per CU, tiles idx = blockIdx.x, + gridDim.x, ...): the tile fills the CU's LDS, so the
+// next tile's granules are fetched into registers while the current tile is processed; the move list of the unit
+// phases is staged in LDS once (a global load in the middle of a tile would drain the prefetch).
+#define TOP_MAX_MOVES 3584
 template <bool INV, int NB>
 __global__ void __launch_bounds__(TL_THREADS)
-    k_top(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, unit_phases up) {
+    k_top(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, unit_phases up, uint32_t ntiles) {
     __shared__ uint32_t lds[(1 << NB) * TL_ROWS];
+    __shared__ uint32_t mvl[TOP_MAX_MOVES];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t rh = blockIdx.x & 1;
-    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
-    tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
-    __syncthreads();
-    if (!INV && up.nsteps) tile_unit_phases(lds, up);
-    top_levels<INV>(lds, d.nb, TW, wave, lane);
-    if (INV && up.nsteps) tile_unit_phases(lds, up);
-    tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
+    uint32_t idx = blockIdx.x;
+    if (idx >= ntiles) return;
+    if (up.nsteps)
+        for (uint32_t i = threadIdx.x; i < up.step_end[up.nsteps - 1]; i += TL_THREADS) mvl[i] = up.list[i];
+    typename tile_regs<(1 << NB) / TL_WAVES>::type v = tile_fetch<NB>(Z, d, tile_base(d, idx >> 1), idx & 1, wave, lane);
+#pragma unroll 1
+    for (; idx < ntiles; idx += gridDim.x) {
+        const uint32_t rh = idx & 1;
+        const uint32_t base_w = tile_base(d, idx >> 1);
+        tile_put<NB>(lds, v, d, wave, lane);
+        __syncthreads();
+        {
+            const uint32_t nidx = idx + gridDim.x < ntiles ? idx + gridDim.x : idx;
+            v = tile_fetch<NB>(Z, d, tile_base(d, nidx >> 1), nidx & 1, wave, lane);
+        }
+        if (!INV && up.nsteps) tile_unit_phases(lds, up, mvl);
+        top_levels<INV>(lds, d.nb, TW, wave, lane);
+        if (INV && up.nsteps) tile_unit_phases(lds, up, mvl);
+        tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1840,6 +1893,7 @@ static fft_plan make_plan(uint32_t m) {
                     u.step_end[u.nsteps++] = (uint32_t)list.size();
                 }
             }
+            if (list.size() > TOP_MAX_MOVES) abort();  // 3328 at m = 25, the largest m with the units in the top pass
         }
     }
     // sub-unit moves of k_conv_unit: conversion of the 256 sub-unit indices of a unit
@@ -1926,17 +1980,18 @@ static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, ui
 }
 
 static void launch_top(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32_t *Z, const unit_phases &up) {
-    const dim3 g(tile_grid(d)), b(TL_THREADS);
+    const uint32_t nt = tile_grid(d);
+    const dim3 g(nt < c->num_cus ? nt : c->num_cus), b(TL_THREADS);
     if (d.nb <= 8) {
         if (inv)
-            SOT_LAUNCH(c, kid, (k_top<true, 8>), g, b, Z, d, c->TW, up);
+            SOT_LAUNCH(c, kid, (k_top<true, 8>), g, b, Z, d, c->TW, up, nt);
         else
-            SOT_LAUNCH(c, kid, (k_top<false, 8>), g, b, Z, d, c->TW, up);
+            SOT_LAUNCH(c, kid, (k_top<false, 8>), g, b, Z, d, c->TW, up, nt);
     } else {
         if (inv)
-            SOT_LAUNCH(c, kid, (k_top<true, 9>), g, b, Z, d, c->TW, up);
+            SOT_LAUNCH(c, kid, (k_top<true, 9>), g, b, Z, d, c->TW, up, nt);
         else
-            SOT_LAUNCH(c, kid, (k_top<false, 9>), g, b, Z, d, c->TW, up);
+            SOT_LAUNCH(c, kid, (k_top<false, 9>), g, b, Z, d, c->TW, up, nt);
     }
 }
 
