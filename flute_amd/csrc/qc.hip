@@ -25,6 +25,11 @@
 #include "sot_internal.h"
 
 #define ROWS 128  // bit rows of a Block
+#ifndef QC_EXP
+// profiling experiments only (tools_exp.sh; results are wrong when set): 1 = k_fft_low without word levels,
+// 2 = without intra-word levels, 4 = k_qc_finish without the tail sums, 8 = without the transposes
+#define QC_EXP 0
+#endif
 
 static __device__ const uint32_t d_BETA[32] = {
 #include "qc_beta.inc"
@@ -84,14 +89,16 @@ __global__ void k_set_points(blk_t *__restrict__ V, const uint64_t *__restrict__
 // K1: Blocks -> row words. Z[w * ROWS + row] bit p = bit `row` of V1'[32 w + p],
 // V1'[c] = V1[c] ^ V1[c + P] (reduction mod x^P - 1 of the 2*n_blocks*128-bit row), c < lo_bits; zero above.
 // One workgroup per 64 words (2048 Blocks in, 32 KiB out); both sides coalesced through LDS.
-#define LD_W 64
-__global__ void __launch_bounds__(256)
+// One workgroup (128 threads) per 32 words (1024 Blocks in, 16 KiB out); both sides coalesced through one LDS
+// buffer used in place (the kernel is latency bound: small workgroups, many per CU).
+#define LD_W 32
+#define LD_T 128
+__global__ void __launch_bounds__(LD_T)
     k_qc_load(const blk_t *__restrict__ V1, uint64_t v1_len, uint64_t P, uint64_t lo_bits, uint64_t nw_half,
               uint32_t *__restrict__ Z) {
-    __shared__ uint32_t tin[LD_W * 132];   // [w][p][q] words, 132-word stride: conflict-free column reads
-    __shared__ uint32_t tout[LD_W * 129];  // [w][row]
+    __shared__ uint32_t tio[LD_W * 132];  // in: [w][p][q] words (stride 132); out: [w][row] (stride 129)
     const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
-    for (uint32_t i = threadIdx.x; i < LD_W * 32; i += 256) {
+    for (uint32_t i = threadIdx.x; i < LD_W * 32; i += LD_T) {
         const uint64_t c = w0 * 32 + i;
         blk_t v = make_uint4(0, 0, 0, 0);
         if (c < lo_bits) {
@@ -101,7 +108,7 @@ __global__ void __launch_bounds__(256)
                 v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
             }
         }
-        uint32_t *d = tin + (i >> 5) * 132 + (i & 31) * 4;
+        uint32_t *d = tio + (i >> 5) * 132 + (i & 31) * 4;
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     }
     __syncthreads();
@@ -109,15 +116,16 @@ __global__ void __launch_bounds__(256)
         const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
         uint32_t a[32];
 #pragma unroll
-        for (int p = 0; p < 32; p++) a[p] = tin[wl * 132 + p * 4 + q];
+        for (int p = 0; p < 32; p++) a[p] = tio[wl * 132 + p * 4 + q];
         transpose32(a);
+        __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 32; b++) tout[wl * 129 + 32 * q + b] = a[b];
+        for (int b = 0; b < 32; b++) tio[wl * 129 + 32 * q + b] = a[b];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += 256) {
+    for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += LD_T) {
         const uint64_t w = w0 + (i >> 7);
-        if (w < nw_half) Z[w * ROWS + (i & 127)] = tout[(i >> 7) * 129 + (i & 127)];
+        if (w < nw_half) Z[w * ROWS + (i & 127)] = tio[(i >> 7) * 129 + (i & 127)];
     }
 }
 
@@ -134,11 +142,12 @@ __global__ void k_a_load(const uint32_t *__restrict__ abits, uint64_t nbits, uin
 }
 
 // K9: row words -> Blocks: T[32 w + p] bit row = Z[w][row] bit p.
+#define ST_W 64
 __global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ Z, uint64_t nw, blk_t *__restrict__ T) {
-    __shared__ uint32_t tin[LD_W * 129];   // [w][row]
-    __shared__ uint32_t tout[LD_W * 132];  // [w][p][q]
-    const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
-    for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += 256) {
+    __shared__ uint32_t tin[ST_W * 129];   // [w][row]
+    __shared__ uint32_t tout[ST_W * 132];  // [w][p][q]
+    const uint64_t w0 = (uint64_t)blockIdx.x * ST_W;
+    for (uint32_t i = threadIdx.x; i < ST_W * ROWS; i += 256) {
         const uint64_t w = w0 + (i >> 7);
         tin[(i >> 7) * 129 + (i & 127)] = w < nw ? Z[w * ROWS + (i & 127)] : 0u;
     }
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ Z
         for (int p = 0; p < 32; p++) tout[wl * 132 + p * 4 + q] = a[p];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < LD_W * 32; i += 256) {
+    for (uint32_t i = threadIdx.x; i < ST_W * 32; i += 256) {
         const uint64_t c = w0 * 32 + i;
         if (c < nw * 32) {
             const uint32_t *s = tout + (i >> 5) * 132 + (i & 31) * 4;
@@ -1397,9 +1406,6 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t rh = blockIdx.x & 1;
     const uint32_t o = blockIdx.x >> 1;
     const uint32_t base_w = tile_base(d, o);
-#ifndef QC_EXP
-#define QC_EXP 0  // profiling experiments only (tools_exp.sh): 1 = no word levels, 2 = no intra-word levels
-#endif
     const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
     // first mask lines of this wave's value word (see mask_prefetch); issued before the tile's own loads, so they
     // are older than every load the compiler tracks
@@ -1555,15 +1561,19 @@ __global__ void __launch_bounds__(256)
 #define FN_W 16
 #define FN_K (FN_W * 32)
 #define FN_TAILMAX 256
+static inline size_t fn_dyn_lds(uint32_t tail) {
+    return tail ? (size_t)(FN_K + 2 * tail) * 16 + ((FN_K + tail + 15) & ~15u) : 0;
+}
 __global__ void __launch_bounds__(256)
     k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, uint64_t nb128, uint64_t P,
                 uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2, const uint32_t *__restrict__ a_hi,
                 blk_t *__restrict__ out) {
-    __shared__ uint32_t tin[FN_W * 129];   // [w][row]
-    __shared__ uint32_t tout[FN_W * 132];  // [w][p][q]
-    __shared__ blk_t win[FN_K + FN_TAILMAX];   // V1'[(c0 + x) mod P]
-    __shared__ blk_t hi[FN_TAILMAX];           // V1'[S + j]
-    __shared__ uint8_t abit[FN_K + FN_TAILMAX];  // a_lo[(c0 + x) mod P]
+    __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
+    // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
+    extern __shared__ blk_t fn_dyn[];
+    blk_t *win = fn_dyn;                                    // [FN_K + tail]  V1'[(c0 + x) mod P]
+    blk_t *hi = fn_dyn + FN_K + tail;                       // [tail]         V1'[S + j]
+    uint8_t *abit = (uint8_t *)(fn_dyn + FN_K + 2 * tail);  // [FN_K + tail]  0xff * a_lo[(c0 + x) mod P]
     const blk_t *V1 = V + nb128;
     const uint64_t k0 = (uint64_t)blockIdx.x * FN_K;
     const uint64_t w0 = k0 >> 5;
@@ -1580,47 +1590,41 @@ __global__ void __launch_bounds__(256)
             uint32_t hi1 = (sh && w1 + 1 < nw) ? Z[(w1 + 1) * ROWS + row] : 0u;
             v ^= sh ? ((lo >> sh) | (hi1 << (32 - sh))) : lo;
         }
-        tin[(i >> 7) * 129 + row] = v;
+        tio[(i >> 7) * 129 + row] = v;
     }
-    uint64_t c0 = 0;
-    if (tail) {
+    if (tail && !(QC_EXP & 4)) {
         const uint64_t q0 = k0 >= S ? k0 - S : k0 + P - S;  // k0 < n <= P
-        c0 = (q0 + P - (tail - 1)) % P;
+        const uint64_t c0 = (q0 + P - (tail - 1)) % P;
         for (uint32_t x = threadIdx.x; x < FN_K + tail - 1; x += 256) {
             uint64_t cc = c0 + x;
             if (cc >= P) cc -= P;
-            blk_t v = V1[cc];
-            if (cc + P < nb128) {
-                blk_t u = V1[cc + P];
-                v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
-            }
-            win[x] = v;
-            abit[x] = cc < S ? (uint8_t)((a2[cc >> 5] >> (cc & 31)) & 1u) : (uint8_t)0;
+            win[x] = ld_v1p(V1, nb128, P, cc);
+            abit[x] = cc < S ? (uint8_t)(0u - ((a2[cc >> 5] >> (cc & 31)) & 1u)) : (uint8_t)0;
         }
-        for (uint32_t j = threadIdx.x; j < tail; j += 256) {
-            blk_t v = V1[S + j];
-            if (S + j + P < nb128) {
-                blk_t u = V1[S + j + P];
-                v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
-            }
-            hi[j] = v;
-        }
+        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V1, nb128, P, S + j);
     }
     __syncthreads();
-    if (threadIdx.x < FN_W * 4) {
+    {
+        // 32x32 bit transposes through registers, in place (128 of the 256 threads: word wl, quarter q of the rows)
         const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const bool act = threadIdx.x < FN_W * 4 && !(QC_EXP & 8);
         uint32_t a[32];
+        if (act) {
 #pragma unroll
-        for (int b = 0; b < 32; b++) a[b] = tin[wl * 129 + 32 * q + b];
-        transpose32(a);
+            for (int b = 0; b < 32; b++) a[b] = tio[wl * 129 + 32 * q + b];
+            transpose32(a);
+        }
+        __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int p = 0; p < 32; p++) tout[wl * 132 + p * 4 + q] = a[p];
+            for (int p = 0; p < 32; p++) tio[wl * 132 + p * 4 + q] = a[p];
+        }
     }
     __syncthreads();
     for (uint32_t kl = threadIdx.x; kl < FN_K; kl += 256) {
         const uint64_t k = k0 + kl;
         if (k >= n) break;
-        const uint32_t *sp = tout + (kl >> 5) * 132 + (kl & 31) * 4;
+        const uint32_t *sp = tio + (kl >> 5) * 132 + (kl & 31) * 4;
         blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
         blk_t u = V[k];
         r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
@@ -1628,17 +1632,17 @@ __global__ void __launch_bounds__(256)
             u = V[k + P];
             r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         }
-        if (tail) {
+        if (tail && !(QC_EXP & 4)) {
+            // branch-free in the lanes: a wave-uniform test of a_hi[i], a per-lane byte mask for a_lo
             const uint32_t xb = kl + tail - 1;  // x = xb - i
             for (uint32_t i = 0; i < tail; i++) {
                 if ((a_hi[i >> 5] >> (i & 31)) & 1u) {  // wave-uniform
                     u = win[xb - i];
                     r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
                 }
-                if (abit[xb - i]) {
-                    u = hi[i];
-                    r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-                }
+                const uint32_t m = (uint32_t)(int32_t)(int8_t)abit[xb - i];
+                u = hi[i];
+                r.x = XAND(r.x, u.x, m), r.y = XAND(r.y, u.y, m), r.z = XAND(r.z, u.z, m), r.w = XAND(r.w, u.w, m);
             }
         }
         out[k] = r;
@@ -2142,7 +2146,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
         SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), V, c->d_points,
                            (uint32_t)npoints, nV);
     }
-    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(256), V + nb128, nb128, cf.P, g.lo_bits,
+    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V + nb128, nb128, cf.P, g.lo_bits,
                g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
@@ -2155,8 +2159,10 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
         sot_set_error("internal: tail exceeds FN_TAILMAX");
         return SOT_EINVAL;
     }
-    SOT_LAUNCH(c, KID_QC_FINAL, k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), zb[cur], g.nw, V, nb128, cf.P, g.S,
-               (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
+    if (c->prof) prof_begin(c, KID_QC_FINAL);
+    hipLaunchKernelGGL(k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
+                       g.nw, V, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
+    if (c->prof) prof_end(c, KID_QC_FINAL);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[role].encoded = true;
