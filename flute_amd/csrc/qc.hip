@@ -683,51 +683,87 @@ __device__ __forceinline__ void ty_fold(u4 *lds, const taylor_desc &t, bool wrap
     }
 }
 
+// element `it` (of the 8192 of a tile) of tile `b`, zero outside the unit
+__device__ __forceinline__ u4 ty_ld(const uint32_t *__restrict__ Din, const taylor_desc &t, uint32_t ncoltiles, uint32_t b,
+                                    uint32_t it) {
+    const uint32_t UW = 1u << (t.lus - 5);  // words per unit
+    const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
+    const uint32_t nrg = 32u >> t.lrq;  // row groups
+    const uint32_t rg = b % nrg, cb = (b / nrg) % ncoltiles, grp = (b / nrg) / ncoltiles;
+    const uint32_t o0 = cb * W;
+    const bool wrap = o0 == 0;
+    const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
+    const uint32_t r = it & ((1u << t.lrq) - 1u);
+    const uint32_t col = (it >> t.lrq) & (NC - 1);
+    const uint32_t u = it >> (t.lrq + t.lnc);
+    const uint32_t o = col >= t.hw ? o0 + col - t.hw : (wrap ? UW - t.hw + col : o0 - t.hw + col);
+    u4 v = {0, 0, 0, 0};
+    if (o < UW) v = ld_u4(Din + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r);
+    return v;
+}
+__device__ __forceinline__ cu_regs ty_fetch_tile(const uint32_t *__restrict__ Din, const taylor_desc &t, uint32_t ncoltiles,
+                                                 uint32_t b) {
+    cu_regs x;
+    const uint32_t i = threadIdx.x;
+    x.a = ty_ld(Din, t, ncoltiles, b, i), x.b = ty_ld(Din, t, ncoltiles, b, i + CT_THREADS);
+    x.c = ty_ld(Din, t, ncoltiles, b, i + 2 * CT_THREADS), x.d = ty_ld(Din, t, ncoltiles, b, i + 3 * CT_THREADS);
+    x.e = ty_ld(Din, t, ncoltiles, b, i + 4 * CT_THREADS), x.f = ty_ld(Din, t, ncoltiles, b, i + 5 * CT_THREADS);
+    x.g = ty_ld(Din, t, ncoltiles, b, i + 6 * CT_THREADS), x.h = ty_ld(Din, t, ncoltiles, b, i + 7 * CT_THREADS);
+    return x;
+}
+
+// Persistent (one workgroup per CU, tiles b = blockIdx.x, + gridDim.x, ...; a tile is always 8192 elements = 8 per
+// thread): the next tile is fetched into registers while the phases of the current one run in LDS.
 __global__ void __launch_bounds__(CT_THREADS)
     k_conv_taylor(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, taylor_desc t, uint32_t ncoltiles,
-                  int inverse) {
+                  int inverse, uint32_t ntiles) {
     __shared__ u4 lds[8192];
     const uint32_t UW = 1u << (t.lus - 5);  // words per unit
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
     const uint32_t nrg = 32u >> t.lrq;  // row groups
-    const uint32_t rg = blockIdx.x % nrg;
-    const uint32_t cb = (blockIdx.x / nrg) % ncoltiles;
-    const uint32_t grp = (blockIdx.x / nrg) / ncoltiles;
-    const uint32_t o0 = cb * W;
-    const bool wrap = o0 == 0;
-    const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
-    const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);
-    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        const uint32_t r = it & ((1u << t.lrq) - 1u);
-        const uint32_t col = (it >> t.lrq) & (NC - 1);
-        const uint32_t u = it >> (t.lrq + t.lnc);
-        const uint32_t o = col >= t.hw ? o0 + col - t.hw : (wrap ? UW - t.hw + col : o0 - t.hw + col);
-        u4 v = {0, 0, 0, 0};
-        if (o < UW) v = *(const u4 *)(Din + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r);
-        lds[it] = v;
-    }
-    __syncthreads();
-    for (uint32_t q = 0; q < t.nph; q++) {
-        const uint32_t i = inverse ? t.nph - 1 - q : q;
-        const uint32_t lchunk = t.lchunk[i], lpw = t.lpw[i];
-        if (!inverse) {
-            ty_fold(lds, t, wrap, lchunk, lpw);
-            __syncthreads();
-            ty_shift(lds, t, wrap, lchunk, lpw);
-        } else {
-            ty_shift(lds, t, wrap, lchunk, lpw);
-            __syncthreads();
-            ty_fold(lds, t, wrap, lchunk, lpw);
+    const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);  // == 8192 (make_taylor)
+    uint32_t b = blockIdx.x;
+    if (b >= ntiles) return;
+    cu_regs nx = ty_fetch_tile(Din, t, ncoltiles, b);
+#pragma unroll 1
+    for (; b < ntiles; b += gridDim.x) {
+        const uint32_t rg = b % nrg;
+        const uint32_t cb = (b / nrg) % ncoltiles;
+        const uint32_t grp = (b / nrg) / ncoltiles;
+        const uint32_t o0 = cb * W;
+        const bool wrap = o0 == 0;
+        const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
+        {
+            const uint32_t i = threadIdx.x;
+            lds[i] = nx.a, lds[i + CT_THREADS] = nx.b, lds[i + 2 * CT_THREADS] = nx.c, lds[i + 3 * CT_THREADS] = nx.d;
+            lds[i + 4 * CT_THREADS] = nx.e, lds[i + 5 * CT_THREADS] = nx.f, lds[i + 6 * CT_THREADS] = nx.g;
+            lds[i + 7 * CT_THREADS] = nx.h;
         }
         __syncthreads();
-    }
-    for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-        const uint32_t r = it & ((1u << t.lrq) - 1u);
-        const uint32_t col = (it >> t.lrq) & (NC - 1);
-        const uint32_t u = it >> (t.lrq + t.lnc);
-        if (col < t.hw) continue;
-        const uint32_t o = o0 + col - t.hw;
-        if (o < UW) *(u4 *)(Dout + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r) = lds[it];
+        nx = ty_fetch_tile(Din, t, ncoltiles, b + gridDim.x < ntiles ? b + gridDim.x : b);
+        for (uint32_t q = 0; q < t.nph; q++) {
+            const uint32_t i = inverse ? t.nph - 1 - q : q;
+            const uint32_t lchunk = t.lchunk[i], lpw = t.lpw[i];
+            if (!inverse) {
+                ty_fold(lds, t, wrap, lchunk, lpw);
+                __syncthreads();
+                ty_shift(lds, t, wrap, lchunk, lpw);
+            } else {
+                ty_shift(lds, t, wrap, lchunk, lpw);
+                __syncthreads();
+                ty_fold(lds, t, wrap, lchunk, lpw);
+            }
+            __syncthreads();
+        }
+        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
+            const uint32_t r = it & ((1u << t.lrq) - 1u);
+            const uint32_t col = (it >> t.lrq) & (NC - 1);
+            const uint32_t u = it >> (t.lrq + t.lnc);
+            if (col < t.hw) continue;
+            const uint32_t o = o0 + col - t.hw;
+            if (o < UW) *(u4 *)(Dout + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r) = lds[it];
+        }
+        __syncthreads();
     }
 }
 
@@ -1766,7 +1802,8 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
     };
     auto run_taylor = [&](const taylor_desc &t, unsigned g, uint32_t nc) {
-        SOT_LAUNCH(c, kid, k_conv_taylor, dim3(g), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], t, nc, inverse ? 1 : 0);
+        SOT_LAUNCH(c, kid, k_conv_taylor, dim3(g < c->num_cus ? g : c->num_cus), dim3(CT_THREADS), bufs[cur], bufs[cur ^ 1], t,
+                   nc, inverse ? 1 : 0, (uint32_t)g);
         cur ^= 1;
     };
     if (!inverse) {
