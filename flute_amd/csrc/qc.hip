@@ -27,7 +27,8 @@
 #define ROWS 128  // bit rows of a Block
 #ifndef QC_EXP
 // profiling experiments only (tools_exp.sh; results are wrong when set): 1 = k_fft_low without word levels,
-// 2 = without intra-word levels, 4 = k_qc_finish without the tail sums, 8 = without the transposes
+// 2 = without intra-word levels, 4 = k_qc_finish without the tail sums, 8 = without the transposes, 16 = k_mid
+// without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
 #define QC_EXP 0
 #endif
 
@@ -1295,59 +1296,91 @@ __device__ __forceinline__ void apply_masks16(uint32_t acc[16], const uint32_t y
     }
 }
 
+// Persistent, two workgroups per CU (tiles idx = blockIdx.x, + gridDim.x, ...): the next tile's 32 granules per
+// thread are fetched while the four levels of the current one run, and the 1 KiB of masks of a level is pulled into
+// L2 one level ahead (mask_prefetch).
 template <bool INV, bool PRUNE_LAST>
 __global__ void __launch_bounds__(MD_THREADS)
-    k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT) {
+    k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT, uint32_t ntiles) {
     __shared__ uint32_t lds[256 * TL_ROWS];
+    constexpr int PER = 256 / MD_WAVES;
+    typedef typename tile_regs<PER>::type regs_t;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t rh = blockIdx.x & 1;
-    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
-    {
-        constexpr int PER = 256 / MD_WAVES;
-        const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
-        uint32_t v[PER];
+    auto fetch = [&](uint32_t idx) {
+        const uint32_t *g = Z + (uint64_t)(tile_base(d, idx >> 1) | tile_word(d, wave)) * ROWS + (idx & 1) * TL_ROWS + lane;
+        regs_t v;
 #pragma unroll
         for (int i = 0; i < PER; i++) v[i] = g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS];
+        return v;
+    };
+    // a workgroup takes BOTH row halves of a tile back to back (sequence s: tile pair blockIdx.x + (s / 2) gridDim.x,
+    // half s % 2): the second half finds the tile's masks in L2
+    const uint32_t npairs = ntiles >> 1;
+    if (blockIdx.x >= npairs) return;
+    const uint32_t nseq = 2 * ((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    auto tile_of = [&](uint32_t sq) { return 2 * (blockIdx.x + (sq >> 1) * gridDim.x) + (sq & 1); };
+    uint32_t idx = tile_of(0);
+    const uint32_t bf = wave;
+    // the 4 x 1 KiB of masks of a tile (level lane / 16, line lane % 16), touched one tile ahead; pf stays live up to
+    // the drain at the end of the kernel (see mask_prefetch)
+    auto masks_ahead = [&](uint32_t &pf, uint32_t i2) {
+        const uint32_t o2 = pext32(tile_base(d, i2 >> 1), mask_hi);
+        mask_prefetch(pf, MT + ((((uint64_t)o2 * 4 + (lane >> 4)) * 8 + bf) << 8) + (lane & 15) * 16);
+    };
+    uint32_t pf = 0;
+    masks_ahead(pf, idx);
+    regs_t v = fetch(idx);
+#pragma unroll 1
+    for (uint32_t sq = 0; sq < nseq; sq++) {
+        idx = tile_of(sq);
+        const uint32_t rh = idx & 1;
+        const uint32_t base_w = tile_base(d, idx >> 1);
+        const uint32_t outer = pext32(base_w, mask_hi);
 #pragma unroll
         for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
-    }
-    const uint32_t outer = pext32(base_w, mask_hi);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = INV ? 3 - q : q;
-        const bool pruned = PRUNE_LAST && b == 3;
-        const uint32_t bf = wave;
-        const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
-        uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
-        uint32_t *py = px + (16u << b) * TL_ROWS;
-        const uint32_t *M = MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8);
-        uint32_t x[16], y[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            x[k] = px[k * TL_ROWS];
-            y[k] = py[k * TL_ROWS];
+        __syncthreads();
+        {
+            const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
+            v = fetch(nidx);
+            if (!(nidx & 1)) masks_ahead(pf, nidx);
         }
-        if (INV && !pruned) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) y[k] ^= x[k];
+        for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
+            const int b = INV ? 3 - q : q;
+            const bool pruned = PRUNE_LAST && b == 3;
+            const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
+            uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
+            uint32_t *py = px + (16u << b) * TL_ROWS;
+            const uint32_t *M = MT + ((QC_EXP & 32) ? 0 : ((((uint64_t)outer * 4 + b) * 8 + bf) << 8));
+            uint32_t x[16], y[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                x[k] = px[k * TL_ROWS];
+                y[k] = py[k * TL_ROWS];
+            }
+            if (INV && !pruned) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) y[k] ^= x[k];
+            }
+            apply_masks16(x, y, M);
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
+            if (!pruned) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) py[k * TL_ROWS] = INV ? y[k] : y[k] ^ x[k];
+            }
+            if (!(QC_EXP & 64)) __syncthreads();
         }
-        apply_masks16(x, y, M);
+        {
+            uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
 #pragma unroll
-        for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
-        if (!pruned) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) py[k * TL_ROWS] = INV ? y[k] : y[k] ^ x[k];
+            for (int i = 0; i < PER; i++)
+                g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS] = lds[(wave + MD_WAVES * i) * TL_ROWS + lane];
         }
         __syncthreads();
     }
-    {
-        constexpr int PER = 256 / MD_WAVES;
-        uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
-#pragma unroll
-        for (int i = 0; i < PER; i++) g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS] = lds[(wave + MD_WAVES * i) * TL_ROWS + lane];
-    }
+    mask_prefetch_drain(pf);
 }
 
 // MT[((outer * 4 + b) * 8 + bf)][j][k] = all-ones iff output plane k of (twiddle (x) y) takes input plane j
@@ -2037,22 +2070,26 @@ static void launch_top(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32
 }
 
 // forward butterflies of an operand (upper half of the row zero) on Z, up to (not including) the low kernel
+static inline unsigned mid_grid(const sot_ctx *c, const tile_desc &d) {
+    const unsigned np = tile_grid(d) / 2, cap = 2 * c->num_cus;  // tile pairs; two 64 KiB workgroups per CU
+    return np < cap ? np : cap;
+}
 static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int upto = 3) {
     tile_desc top = p.top;
     top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
     launch_top(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
     if (upto >= 2)
-        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
     if (upto >= 3) {
-        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(tile_grid(p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2);
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
         for (auto &d : p.w32) launch_tile(c, KID_FFT_MID, false, d, Z, p.up_none);
     }
 }
 
 static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
     for (size_t i = p.w32.size(); i-- > 0;) launch_tile(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(tile_grid(p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2);
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(tile_grid(p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1);
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
     launch_top(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
