@@ -31,6 +31,9 @@
 // without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
 #define QC_EXP 0
 #endif
+#ifndef QC_LOWMASK_LDS
+#define QC_LOWMASK_LDS 1  // k_fft_low<1>: intra-word masks through LDS (1) or through the scalar unit (0)
+#endif
 
 static __device__ const uint32_t d_BETA[32] = {
 #include "qc_beta.inc"
@@ -1124,6 +1127,49 @@ __device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
     }
 }
 
+// The same level with its 16 x 32 masks read from LDS (M: 128 uint4, row j = M[8 j .. 8 j + 7]) as VGPR operands:
+// no scalar-memory stream, whose two rows in flight cannot cover the latency of a table that does not fit any cache.
+template <int NJ>
+__device__ __forceinline__ void apply_masks_lds(uint32_t acc[32], const uint32_t v[NJ], const uint4 *M) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+        for (int kq = 0; kq < 8; kq++) {
+            const uint4 m = M[j * 8 + kq];
+            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
+            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
+            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
+            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], v[j], m.w);
+        }
+    }
+}
+template <int I, bool INV>
+__device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
+    const uint32_t A = lowmask(I);
+    constexpr int SH = 1 << I;
+    if (INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
+    }
+    uint32_t P[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) P[j] = BFI(W[j] >> SH, W[j + 16], A);
+    uint32_t acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0;
+    apply_masks_lds<16>(acc, P, M);
+#pragma unroll
+    for (int k = 0; k < 32; k++) W[k] = XAND(W[k], acc[k] ^ (acc[k] >> SH), A);
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
+    }
+}
+// mask blocks of a value word in the order the fused kernel consumes them (2 KiB each): forward levels 4..0, the two
+// halves of Amat, inverse levels 0..4. Word offset into LM (levels) or Amat.
+__device__ __forceinline__ constexpr int lowblk_level(int b) { return b < 5 ? 4 - b : b - 7; }
+__device__ __forceinline__ constexpr bool lowblk_is_amat(int b) { return b == 5 || b == 6; }
+
 // ------------------------------------------------------------------------------------------------
 // K4t: the top pass: whole-unit conversion phases + levels 1..8 (1 and 2 only relabel bits as planes).
 // Tile bits: t0..t3 = planes (levels 1, 2, 4, 8), t4..t7 = levels 3, 5, 6, 7, t8 = an extra unit-index bit (m = 25).
@@ -1479,7 +1525,8 @@ __global__ void __launch_bounds__(TL_THREADS)
     // first mask lines of this wave's value word (see mask_prefetch); issued before the tile's own loads, so they
     // are older than every load the compiler tracks
     uint32_t pf = 0;
-    if (wave < nvw) mask_prefetch(pf, LM + ((uint64_t)o * nvw + wave) * (5 * 512) + 3 * 512 + lane * 16);  // levels 3, 4
+    if (wave < nvw && !(MODE == 1 && QC_LOWMASK_LDS))
+        mask_prefetch(pf, LM + ((uint64_t)o * nvw + wave) * (5 * 512) + 3 * 512 + lane * 16);  // levels 3, 4
     tile_load<9>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
     if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
@@ -1491,6 +1538,55 @@ __global__ void __launch_bounds__(TL_THREADS)
         // The 14 KiB of masks of this value word are streamed once through the scalar unit, two 128-B rows in
         // flight: far too little to cover an HBM miss. Vector loads that touch the lines ahead of time (one lane
         // per 64-B line, result unused) pull them into L2 one to two levels before the scalar loads arrive.
+        if (MODE == 1 && QC_LOWMASK_LDS) {
+            // While W is in registers the 8 KiB of this value word in LDS are free and private to the wave: a ring of
+            // four 2 KiB mask blocks, filled three blocks ahead with plain vector loads (2 x 16 B per lane and block).
+            uint4 *R = (uint4 *)(lds + (vi << 5) * TL_ROWS);
+            auto src = [&](int b) {
+                return (const uint4 *)(lowblk_is_amat(b) ? A + (b - 5) * 512 : L + lowblk_level(b) * 512) + lane;
+            };
+            uint4 s0[3], s1[3];
+#pragma unroll
+            for (int b = 0; b < 3; b++) s0[b] = src(b)[0], s1[b] = src(b)[64];
+            uint32_t W[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
+#pragma unroll
+            for (int b = 0; b < 3; b++) R[b * 128 + lane] = s0[b], R[b * 128 + 64 + lane] = s1[b];
+            uint32_t t[32];
+#pragma unroll
+            for (int b = 0; b < 12; b++) {
+                uint4 n0, n1;
+                if (b + 3 < 12) n0 = src(b + 3)[0], n1 = src(b + 3)[64];
+                const uint4 *M = R + (b & 3) * 128;
+                switch (b) {
+                    case 0: low_level_lds<4, false>(W, M); break;
+                    case 1: low_level_lds<3, false>(W, M); break;
+                    case 2: low_level_lds<2, false>(W, M); break;
+                    case 3: low_level_lds<1, false>(W, M); break;
+                    case 4: low_level_lds<0, false>(W, M); break;
+                    case 5:
+#pragma unroll
+                        for (int k = 0; k < 32; k++) t[k] = 0;
+                        apply_masks_lds<16>(t, W, M);
+                        break;
+                    case 6:
+                        apply_masks_lds<16>(t, W + 16, M);
+#pragma unroll
+                        for (int k = 0; k < 32; k++) W[k] = t[k];
+                        break;
+                    case 7: low_level_lds<0, true>(W, M); break;
+                    case 8: low_level_lds<1, true>(W, M); break;
+                    case 9: low_level_lds<2, true>(W, M); break;
+                    case 10: low_level_lds<3, true>(W, M); break;
+                    default: low_level_lds<4, true>(W, M); break;
+                }
+                if (b + 3 < 12) R[((b + 3) & 3) * 128 + lane] = n0, R[((b + 3) & 3) * 128 + 64 + lane] = n1;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
+            continue;
+        }
         const uint32_t l16 = lane * 16, h16 = (lane & 31) * 16;
         if (vi != wave) mask_prefetch(pf, L + 3 * 512 + l16);  // levels 3, 4
         uint32_t W[32];
