@@ -65,8 +65,7 @@ def main():
             "fetch_size_kib_raw": e["FETCH_SIZE"], "write_size_kib": e["WRITE_SIZE"],
             "dominant_traffic_bytes_per_launch": e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024,
             "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 tallies 128-B "
-                    "requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch of " + dom + "; an upper "
-                    "bound: the kernel also streams its mask tables through 64-B scalar loads, which the x2 over-corrects",
+                    "requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, per launch of " + dom + ": 512 MiB of bit rows + the per-value-word mask tables (LM, Amat) streamed once per row half",
         }
         with open(os.path.join(os.path.dirname(prefix), "pmc_latest.json"), "w") as f:
             json.dump(out, f, indent=1)
