@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=24,
                     help="CPU baseline sample size (2^24 = the GPU workload itself, about 10-20 s on 16 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
@@ -114,12 +116,21 @@ def main():
     tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads)
     pts = eng.points(y[2])
 
+    # N > 1: every step ends with the one exchange of the path, the all-gather (RCCL over xGMI) that leaves the
+    # party's whole MT store -- a | b | c of every rank's instance, 6 MiB per rank -- on every GPU
+    gather = {"on": world > 1 and not args.no_gather, "buf": None, "note": None}
+
     def step():
         eng.sender_expand(x[0], delta, seed, args.threads)
         eng.qc_encode(0)
         eng.receiver_expand(y[1], y[2], *tg_y)
         eng.qc_encode(1, pts)
         eng.mt_bits(delta, download=False)
+        if gather["on"]:
+            try:
+                _, gather["buf"] = fd.gather_mt_store(eng, world, gather["buf"])
+            except Exception as e:  # same code on every rank: an API-level failure is symmetric, so all ranks fall back
+                gather["on"], gather["note"] = False, "all-gather failed and was disabled: %r" % (e,)
 
     def barrier():
         eng.sync()
@@ -169,8 +180,11 @@ def main():
             "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, n=2^%d random OTs per direction, "
                                    "sender+receiver expansion + MT bits on each GPU" % args.log2n,
                        "P": conf.P, "trees": conf.parts, "depth": conf.depth, "threads_T": args.threads,
-                       "sharding": "independent instances per rank (no collective)"},
+                       "sharding": ("independent instances per rank; MT store (3 x 2 MiB per rank) all-gathered over RCCL "
+                                    "every step" if gather["on"] else "independent instances per rank (no collective)")},
         }
+        if gather["note"]:
+            out["config"]["gather_note"] = gather["note"]
         if prof:
             per_step = {k: (ms / args.steps, cnt // args.steps) for k, (ms, cnt) in prof.items()}
             qc_ms = sum(ms for k, (ms, _) in per_step.items() if k in QC_KERNELS)

@@ -363,6 +363,24 @@ extern "C" int sot_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t 
     return hash_mt_bits(c, delta, a, b, cc);
 }
 
+extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_bytes) {
+    CHECK_CTX(c);
+    const uint64_t bytes = 3 * ((c->conf.n + 63) / 64) * 8;
+    if (!dst_device || dst_bytes < bytes) {
+        sot_set_error("mt_bits_to_device: destination of %llu bytes, need %llu", (unsigned long long)dst_bytes,
+                      (unsigned long long)bytes);
+        return SOT_EINVAL;
+    }
+    if (!c->mt_valid) {
+        sot_set_error("mt_bits_to_device before sot_mt_bits");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    SOT_HIP(hipMemcpyAsync(dst_device, c->d_mt, bytes, hipMemcpyDeviceToDevice, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
 extern "C" int sot_random_silent_send(sot_ctx *c, const void *base_ots, const void *delta, const void *seed,
                                       uint64_t num_threads, void *tg_sums_out, void *tg_last_out, void *msgs_out) {
     SOT_TRY(sot_sender_expand(c, base_ots, delta, seed, num_threads, tg_sums_out, tg_last_out));

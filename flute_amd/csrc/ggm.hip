@@ -436,6 +436,7 @@ int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[SOT_ROLE_SENDER].expanded = true;
     c->role[SOT_ROLE_SENDER].encoded = false;
+    c->mt_valid = false;
     return SOT_OK;
 }
 
@@ -464,6 +465,7 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[SOT_ROLE_RECEIVER].expanded = true;
     c->role[SOT_ROLE_RECEIVER].encoded = false;
+    c->mt_valid = false;
     return SOT_OK;
 }
 
@@ -559,6 +561,7 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
     SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[0].enc,
                        c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
     SOT_HIP(hipGetLastError());
+    c->mt_valid = true;
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (b) SOT_HIP(hipMemcpyAsync(b, c->d_mt + nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (cc) SOT_HIP(hipMemcpyAsync(cc, c->d_mt + 2 * nw, nw * 8, hipMemcpyDeviceToHost, c->stream));

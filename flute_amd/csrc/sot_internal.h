@@ -116,6 +116,7 @@ struct sot_ctx {
     uint64_t *d_points = nullptr;
     // MT bits
     uint64_t *d_mt = nullptr;  // a | b | c words
+    bool mt_valid = false;     // set by hash_mt_bits, cleared by the next expand
     void *d_tmp = nullptr;     // download staging
     uint64_t tmp_bytes = 0;
     // profiling

@@ -23,6 +23,16 @@ class MulTriples:
         pad = (-len(bits)) % 64
         return np.packbits(np.concatenate([bits, np.zeros(pad, dtype=np.uint8)]), bitorder="little").view(np.uint64)
 
+    @classmethod
+    def from_gathered(cls, words, n):
+        """The party's MT store out of dist.all_gather_words: words[rank] = a | b | c words of that rank's instance
+        (n triples each); the instances are concatenated in rank order, bit-exactly (n need not be a multiple of 64)."""
+        words = np.ascontiguousarray(np.asarray(words)).view(np.uint64)
+        world, nw = words.shape[0], words.shape[1] // 3
+        parts = [[cls._bits(words[r, i * nw:(i + 1) * nw], n) for r in range(world)] for i in range(3)]
+        a, b, c = (cls._pack(np.concatenate(p)) for p in parts)
+        return cls(a, b, c, world * n)
+
     def split_off_last(self, k):
         """mod.rs:172-185: consumers take triples from the END."""
         if k > self.n:

@@ -243,6 +243,15 @@ class Engine:
         return a, b, c
 
 
+    def mt_words(self):
+        """3 * ceil(n / 64): length in u64 of the a | b | c buffer of mt_bits_to_device."""
+        return 3 * ((self.conf.n + 63) // 64)
+
+    def mt_bits_to_device(self, device_ptr, nbytes):
+        """a | b | c words of the last mt_bits() into a caller-owned device buffer (a torch tensor's data_ptr())."""
+        check(self.lib.sot_mt_bits_to_device(self.h, C.c_void_p(device_ptr), nbytes))
+
+
 class Sender:
     """zappot::silent_ot::Sender (mod.rs:49-56)."""
 

@@ -116,6 +116,12 @@ int sot_receiver_hash(sot_ctx *ctx, void *msgs_out, uint64_t *choice_words_out);
  * NULL to leave the bits on the device only. */
 int sot_mt_bits(sot_ctx *ctx, const void *delta, uint64_t *a_out, uint64_t *b_out, uint64_t *c_out);
 
+/* The three MT bit vectors of the last sot_mt_bits, a | b | c (3 * ceil(n/64) u64), copied device-to-device into a
+ * caller-owned DEVICE buffer on the context's GPU (synchronous on return). No counterpart in the reference (its
+ * MulTriples live in host memory, gmw/src/mul_triple/mod.rs:30-35): this is what a multi-GPU party hands to the
+ * RCCL all-gather that reassembles its MT store from the per-GPU instances. */
+int sot_mt_bits_to_device(sot_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+
 /* ---- whole-direction pipelines (random_silent_send / random_silent_receive) --------------- */
 /* silent_ot/mod.rs:193-211. msgs_out may be NULL (results stay in HBM). */
 int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed,

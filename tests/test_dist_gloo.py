@@ -27,7 +27,13 @@ def _worker(rank, world, port, q):
     fd.barrier(world)
     dt = fd.max_over_ranks(0.5 + rank, world)  # rank 1 is the slow one
     val = fd.aggregate_ots_per_s(1 << 24, 10, dt, world)
-    q.put((rank, int(msg2[0, 0, 0]), int(choices.sum()), dt, val))
+    # the one exchange step: all-gather of every rank's a | b | c words (RCCL on GPUs, gloo here)
+    import torch
+    n = 1000
+    nw = (n + 63) // 64
+    local = np.random.default_rng(77 + rank).integers(0, 2 ** 63, 3 * nw, dtype=np.int64)
+    g = fd.all_gather_words(torch.from_numpy(local), world).numpy()
+    q.put((rank, int(msg2[0, 0, 0]), int(choices.sum()), dt, val, g.tobytes()))
     d.destroy_process_group()
 
 
@@ -43,7 +49,18 @@ def test_two_rank_plumbing():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, m0, c0, dt0, v0), (r1, m1, c1, dt1, v1) = res
+    (r0, m0, c0, dt0, v0, g0), (r1, m1, c1, dt1, v1, g1) = res
+    # both ranks hold the same gathered store, in rank order, and it unpacks to the concatenated instances
+    from flute_amd.mul_triple import MulTriples
+    n, nw = 1000, 16
+    exp = np.stack([np.random.default_rng(77 + r).integers(0, 2 ** 63, 3 * nw, dtype=np.int64) for r in range(world)])
+    assert g0 == g1 == exp.tobytes()
+    mts = MulTriples.from_gathered(exp, n)
+    assert len(mts) == world * n
+    bits = MulTriples._bits(mts.b, len(mts))
+    for r in range(world):
+        want = MulTriples._bits(exp[r, nw:2 * nw].view(np.uint64), n)
+        assert np.array_equal(bits[r * n:(r + 1) * n], want)
     assert (r0, r1) == (0, 1)
     assert m0 != m1  # different instances per rank
     assert dt0 == dt1 == 1.5  # max over ranks

@@ -174,3 +174,38 @@ def test_two_party_mt_relation(fa, orc):
     finally:
         e0.close()
         e1.close()
+
+
+def test_mt_store_gather_single_rank(fa, orc):
+    """sot_mt_bits_to_device + dist.gather_mt_store (world 1: the device copy, no collective) hand over exactly the
+    a | b | c words that sot_mt_bits downloads; before mt_bits the call is an ESTATE error."""
+    import torch
+    from flute_amd import dist as fd
+    from flute_amd.lib import SotError
+    n, T = 3000, 2
+    e = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(5)
+        x = fa.fake_base(e.conf, rng)
+        y = fa.fake_base(e.conf, rng)
+        delta, seed, dp, sp = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+        tg_y = e.sender_expand(y[0], dp, sp, T)
+        e.sender_expand(x[0], delta, seed, T)
+        e.qc_encode(0)
+        e.receiver_expand(y[1], y[2], *tg_y)
+        e.qc_encode(1, e.points(y[2]))
+        buf = torch.zeros(e.mt_words(), dtype=torch.int64, device="cuda:0")
+        with pytest.raises(SotError):
+            e.mt_bits_to_device(buf.data_ptr(), buf.numel() * 8)
+        a, b, c = e.mt_bits(delta)
+        with pytest.raises(SotError):
+            e.mt_bits_to_device(buf.data_ptr(), 8)  # too small
+        g, _ = fd.gather_mt_store(e, 1, buf)
+        torch.cuda.synchronize()
+        got = g.cpu().numpy().view(np.uint64)
+        assert got.shape == (1, e.mt_words())
+        assert np.array_equal(got[0], np.concatenate([a, b, c]))
+        mts = fa.MulTriples.from_gathered(got, n)
+        assert len(mts) == n and np.array_equal(mts.c, c)
+    finally:
+        e.close()
