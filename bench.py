@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsals on a 1-GPU box)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
@@ -97,8 +99,11 @@ def main():
         args.gpus = world
 
     import torch
+    if args.device is not None:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
-    dist = fd.init("nccl", rank, world, device_id=torch.device("cuda", local_rank))
+    dist = fd.init(args.backend, rank, world,
+                   device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
 
     import flute_amd as fa
     n = 1 << args.log2n
@@ -180,8 +185,8 @@ def main():
             "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, n=2^%d random OTs per direction, "
                                    "sender+receiver expansion + MT bits on each GPU" % args.log2n,
                        "P": conf.P, "trees": conf.parts, "depth": conf.depth, "threads_T": args.threads,
-                       "sharding": ("independent instances per rank; MT store (3 x 2 MiB per rank) all-gathered over RCCL "
-                                    "every step" if gather["on"] else "independent instances per rank (no collective)")},
+                       "sharding": ("independent instances per rank; MT store (a | b | c, 3n bits per rank) all-gathered over "
+                                    "RCCL every step" if gather["on"] else "independent instances per rank (no collective)")},
         }
         if gather["note"]:
             out["config"]["gather_note"] = gather["note"]
