@@ -33,7 +33,8 @@ const char *const SOT_KID_NAMES[KID_COUNT] = {
     "k_roots",       "k_ggm_level",     "k_ggm_leaf", "k_sender_treegrp", "k_recv_init",  "k_recv_fix",
     "k_recv_last",   "k_transpose_tiles", "k_sender_hash", "k_receiver_hash", "k_mt_bits",  "k_clear_lsb",
     "k_qc_load",     "k_conv_fwd",      "k_conv_fwd_tile", "k_fft_top",     "k_fft_mid",    "k_fft_low_mul",
-    "k_ifft_mid",    "k_ifft_top",      "k_conv_inv_tile", "k_conv_inv",    "k_qc_store",   "k_qc_final"};
+    "k_ifft_mid",    "k_ifft_top",      "k_conv_inv_tile", "k_conv_inv",    "k_qc_store",   "k_qc_final",
+    "k_and_msg",     "k_and_eval"};
 
 static hipEvent_t prof_event(sot_ctx *c) {
     if (!c->prof_free.empty()) {

@@ -562,6 +562,7 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
                        c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
     SOT_HIP(hipGetLastError());
     c->mt_valid = true;
+    c->mt_rem = cf.n;
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (b) SOT_HIP(hipMemcpyAsync(b, c->d_mt + nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (cc) SOT_HIP(hipMemcpyAsync(cc, c->d_mt + 2 * nw, nw * 8, hipMemcpyDeviceToHost, c->stream));

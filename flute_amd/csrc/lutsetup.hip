@@ -1,0 +1,270 @@
+// FLUTE function-dependent setup on gfx950: the AND layers of the subset-product circuit, bit-packed.
+//
+// Reference: LutSetupProvider::setup (gmw/src/protocols/aby2_lut.rs:699-783) builds a BooleanGate circuit with one AND
+// per subset (size >= 2) of every LUT gate's private input masks (setup_data_circ, :321-370) and runs it through
+// Executor<BooleanGmw> (executor.rs:74-193): per layer, split_off_last(count) multiplication triples, compute_msg
+// (boolean_gmw.rs:40-67: d = x ^ a, e = y ^ b per gate), one message exchange, evaluate_interactive (:69-95 and
+// evaluate.rs:12-21: z = D & b ^ E & a ^ c, party 0 also ^ D & E, with D, E the XOR of both parties' d, e).
+//
+// Here the host hands over the circuit in flat form (flute_amd/lut_setup.py: operand ids per gate, gates sorted by
+// (layer, gate id) = the reference's order inside a layer) and the device keeps everything bit-packed:
+//   vals : inputs at bits [0, n_inputs), the outputs of layer L at bits [base[L], base[L] + count[L]), base 64-aligned
+//   MTs  : the context's store a | b | c (sot_mt_bits), consumed from the END: layer with `cnt` gates takes bits
+//          [mt_rem - cnt, mt_rem) in gate order -- MulTriples::split_off_last (mul_triple/mod.rs:172-185) + iter() (:92-99)
+// One thread per gate gathers its two operand bits; a wavefront ballot packs 64 results into one word.
+#include <string.h>
+
+#include <vector>
+
+#include "sot_internal.h"
+
+extern "C" void sot_and_circ_destroy(sot_and_circ *q);
+struct sot_and_circ {
+    sot_ctx *ctx = nullptr;
+    uint32_t n_inputs = 0, n_gates = 0, n_layers = 0;
+    std::vector<uint32_t> count, goff;  // per layer: gates, index of its first gate (execution order)
+    std::vector<uint64_t> base;         // per layer: first value bit (64-aligned)
+    std::vector<uint64_t> mt0;          // per layer: first MT bit it consumed (set by layer_msg)
+    std::vector<uint8_t> msg_done;      // per layer: 1 = message computed, not yet evaluated
+    int64_t msg_layer = -1;             // the layer whose message d_own / e_own hold
+    uint64_t val_words = 0, msg_words = 0;
+    uint32_t *xpos = nullptr, *ypos = nullptr;  // device: operand bit positions per gate
+    uint64_t *vals = nullptr;                   // device
+    uint64_t *d_own = nullptr, *e_own = nullptr, *d_peer = nullptr, *e_peer = nullptr;  // device, msg_words each
+};
+
+__device__ __forceinline__ uint32_t bit_at(const uint64_t *__restrict__ w, uint64_t i) {
+    return (uint32_t)(w[i >> 6] >> (i & 63)) & 1u;
+}
+
+// BooleanGmw::compute_msg (boolean_gmw.rs:40-67) for the gates goff .. goff+cnt-1 of one layer
+__global__ void __launch_bounds__(256)
+    k_and_msg(const uint64_t *__restrict__ vals, const uint32_t *__restrict__ xpos, const uint32_t *__restrict__ ypos,
+              uint32_t goff, uint32_t cnt, const uint64_t *__restrict__ mta, const uint64_t *__restrict__ mtb,
+              uint64_t mt0, uint64_t *__restrict__ dout, uint64_t *__restrict__ eout) {
+    const uint32_t cnt_pad = (cnt + 63) & ~63u;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt_pad; j += gridDim.x * blockDim.x) {
+        uint32_t d = 0, e = 0;
+        if (j < cnt) {
+            const uint32_t x = bit_at(vals, xpos[goff + j]), y = bit_at(vals, ypos[goff + j]);
+            d = x ^ bit_at(mta, mt0 + j);  // and::compute_shares, evaluate.rs:5-9
+            e = y ^ bit_at(mtb, mt0 + j);
+        }
+        const unsigned long long bd = __ballot(d), be = __ballot(e);
+        if ((threadIdx.x & 63) == 0) {
+            dout[j >> 6] = bd;
+            eout[j >> 6] = be;
+        }
+    }
+}
+
+// BooleanGmw::evaluate_interactive (boolean_gmw.rs:69-95) + and::evaluate (evaluate.rs:12-21)
+__global__ void __launch_bounds__(256)
+    k_and_eval(const uint64_t *__restrict__ d0, const uint64_t *__restrict__ e0, const uint64_t *__restrict__ d1,
+               const uint64_t *__restrict__ e1, const uint64_t *__restrict__ mta, const uint64_t *__restrict__ mtb,
+               const uint64_t *__restrict__ mtc, uint64_t mt0, uint32_t cnt, uint32_t party, uint64_t *__restrict__ out) {
+    const uint32_t cnt_pad = (cnt + 63) & ~63u;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt_pad; j += gridDim.x * blockDim.x) {
+        uint32_t z = 0;
+        if (j < cnt) {
+            const uint32_t d = bit_at(d0, j) ^ bit_at(d1, j), e = bit_at(e0, j) ^ bit_at(e1, j);
+            const uint32_t a = bit_at(mta, mt0 + j), b = bit_at(mtb, mt0 + j), c = bit_at(mtc, mt0 + j);
+            z = (d & b) ^ (e & a) ^ c;
+            if (party == 0) z ^= d & e;
+        }
+        const unsigned long long bz = __ballot(z);
+        if ((threadIdx.x & 63) == 0) out[j >> 6] = bz;
+    }
+}
+
+static inline unsigned lgrid(uint32_t cnt) {
+    unsigned g = (cnt + 255) / 256;
+    return g < 1 ? 1 : (g > 8192 ? 8192 : g);
+}
+
+extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gates, uint32_t n_layers,
+                                   const uint32_t *layer_counts, const uint32_t *x_src, const uint32_t *y_src,
+                                   sot_and_circ **out) {
+    if (!c || !out || (n_gates && (!layer_counts || !x_src || !y_src))) return SOT_EINVAL;
+    *out = nullptr;
+    uint64_t tot = 0;
+    for (uint32_t l = 0; l < n_layers; l++) tot += layer_counts[l];
+    if (tot != n_gates || (uint64_t)n_inputs + n_gates + 64ull * (n_layers + 1) >= (1ull << 32)) {
+        sot_set_error("and_circ: layer counts do not add up to n_gates, or more than 2^32 value bits");
+        return SOT_EINVAL;
+    }
+    sot_and_circ *q = new sot_and_circ();
+    q->ctx = c;
+    q->n_inputs = n_inputs, q->n_gates = n_gates, q->n_layers = n_layers;
+    q->count.assign(layer_counts, layer_counts + n_layers);
+    q->goff.resize(n_layers), q->base.resize(n_layers), q->mt0.assign(n_layers, 0), q->msg_done.assign(n_layers, 0);
+    uint64_t bit = ((uint64_t)n_inputs + 63) & ~63ull;
+    uint32_t g = 0, maxc = 0;
+    for (uint32_t l = 0; l < n_layers; l++) {
+        q->goff[l] = g, q->base[l] = bit;
+        g += q->count[l];
+        bit = (bit + q->count[l] + 63) & ~63ull;
+        if (q->count[l] > maxc) maxc = q->count[l];
+    }
+    q->val_words = bit / 64 + 1;
+    q->msg_words = ((uint64_t)maxc + 63) / 64 + 1;
+    // operand ids -> bit positions; an operand must be an input or a gate of an EARLIER layer
+    std::vector<uint32_t> xp(n_gates), yp(n_gates);
+    auto pos_of = [&](uint32_t id, uint32_t layer, uint32_t *pos) {
+        if (id < n_inputs) {
+            *pos = id;
+            return true;
+        }
+        const uint32_t gi = id - n_inputs;
+        if (gi >= n_gates) return false;
+        uint32_t l = 0;
+        while (l + 1 < n_layers && q->goff[l + 1] <= gi) l++;
+        if (l >= layer) return false;
+        *pos = (uint32_t)(q->base[l] + (gi - q->goff[l]));
+        return true;
+    };
+    for (uint32_t l = 0; l < n_layers; l++)
+        for (uint32_t j = 0; j < q->count[l]; j++) {
+            const uint32_t gi = q->goff[l] + j;
+            if (!pos_of(x_src[gi], l, &xp[gi]) || !pos_of(y_src[gi], l, &yp[gi])) {
+                sot_set_error("and_circ: gate %u reads a value that is not an input or an earlier layer's output", gi);
+                delete q;
+                return SOT_EINVAL;
+            }
+        }
+    int rc = hipSetDevice(c->device) == hipSuccess ? SOT_OK : SOT_EDEVICE;
+#define AQ(ptr, bytes) \
+    if (rc == SOT_OK && hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) rc = SOT_ENOMEM
+    AQ(q->xpos, (uint64_t)(n_gates ? n_gates : 1) * 4);
+    AQ(q->ypos, (uint64_t)(n_gates ? n_gates : 1) * 4);
+    AQ(q->vals, q->val_words * 8);
+    AQ(q->d_own, q->msg_words * 8);
+    AQ(q->e_own, q->msg_words * 8);
+    AQ(q->d_peer, q->msg_words * 8);
+    AQ(q->e_peer, q->msg_words * 8);
+#undef AQ
+    if (rc == SOT_OK && n_gates) {
+        if (hipMemcpy(q->xpos, xp.data(), (uint64_t)n_gates * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(q->ypos, yp.data(), (uint64_t)n_gates * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = SOT_EDEVICE;
+    }
+    if (rc == SOT_OK && hipMemset(q->vals, 0, q->val_words * 8) != hipSuccess) rc = SOT_EDEVICE;
+    if (rc != SOT_OK) {
+        sot_set_error("and_circ: device allocation failed");
+        sot_and_circ_destroy(q);
+        return rc;
+    }
+    *out = q;
+    return SOT_OK;
+}
+
+extern "C" void sot_and_circ_destroy(sot_and_circ *q) {
+    if (!q) return;
+    if (q->ctx) (void)hipSetDevice(q->ctx->device);
+    void *ptrs[] = {q->xpos, q->ypos, q->vals, q->d_own, q->e_own, q->d_peer, q->e_peer};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete q;
+}
+
+extern "C" int sot_and_circ_set_inputs(sot_and_circ *q, const uint64_t *input_words) {
+    if (!q || (!input_words && q->n_inputs)) return SOT_EINVAL;
+    sot_ctx *c = q->ctx;
+    SOT_HIP(hipSetDevice(c->device));
+    SOT_HIP(hipMemsetAsync(q->vals, 0, q->val_words * 8, c->stream));
+    if (q->n_inputs) {
+        // dead bits of the last word must be zero: they would alias nothing, but keep the image canonical
+        std::vector<uint64_t> w(input_words, input_words + ((uint64_t)q->n_inputs + 63) / 64);
+        if (q->n_inputs & 63) w.back() &= (1ull << (q->n_inputs & 63)) - 1;
+        SOT_HIP(hipMemcpyAsync(q->vals, w.data(), w.size() * 8, hipMemcpyHostToDevice, c->stream));
+        SOT_HIP(hipStreamSynchronize(c->stream));
+    }
+    std::fill(q->msg_done.begin(), q->msg_done.end(), 0);
+    q->msg_layer = -1;
+    return SOT_OK;
+}
+
+extern "C" int sot_and_circ_layer_msg(sot_and_circ *q, uint32_t layer, uint8_t *d_out, uint8_t *e_out) {
+    if (!q || layer >= q->n_layers) return SOT_EINVAL;
+    sot_ctx *c = q->ctx;
+    const uint32_t cnt = q->count[layer];
+    if (!c->mt_valid || c->mt_rem < cnt) {
+        sot_set_error("and_circ: layer %u needs %u multiplication triples, the store holds %llu", layer, cnt,
+                      (unsigned long long)(c->mt_valid ? c->mt_rem : 0));
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t nw = (c->conf.n + 63) / 64;
+    c->mt_rem -= cnt;  // split_off_last(cnt), executor.rs:139
+    q->mt0[layer] = c->mt_rem;
+    q->msg_done[layer] = 1;
+    q->msg_layer = layer;
+    SOT_LAUNCH(c, KID_AND_MSG, k_and_msg, dim3(lgrid(cnt)), dim3(256), q->vals, q->xpos, q->ypos, q->goff[layer], cnt,
+               c->d_mt, c->d_mt + nw, q->mt0[layer], q->d_own, q->e_own);
+    SOT_HIP(hipGetLastError());
+    const uint64_t nb = ((uint64_t)cnt + 7) / 8;
+    if (d_out) SOT_HIP(hipMemcpyAsync(d_out, q->d_own, nb, hipMemcpyDeviceToHost, c->stream));
+    if (e_out) SOT_HIP(hipMemcpyAsync(e_out, q->e_own, nb, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+static int and_eval_launch(sot_and_circ *q, uint32_t layer, uint32_t party, const uint64_t *pd, const uint64_t *pe) {
+    sot_ctx *c = q->ctx;
+    const uint64_t nw = (c->conf.n + 63) / 64;
+    SOT_LAUNCH(c, KID_AND_EVAL, k_and_eval, dim3(lgrid(q->count[layer])), dim3(256), q->d_own, q->e_own, pd, pe, c->d_mt,
+               c->d_mt + nw, c->d_mt + 2 * nw, q->mt0[layer], q->count[layer], party, q->vals + q->base[layer] / 64);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    q->msg_done[layer] = 0;
+    return SOT_OK;
+}
+
+extern "C" int sot_and_circ_layer_eval(sot_and_circ *q, uint32_t layer, uint32_t party_id, const uint8_t *d_peer,
+                                       const uint8_t *e_peer) {
+    if (!q || layer >= q->n_layers || party_id > 1 || !d_peer || !e_peer) return SOT_EINVAL;
+    if (!q->msg_done[layer]) {
+        sot_set_error("and_circ: layer_eval before layer_msg");
+        return SOT_ESTATE;
+    }
+    sot_ctx *c = q->ctx;
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t nb = ((uint64_t)q->count[layer] + 7) / 8;
+    SOT_HIP(hipMemsetAsync(q->d_peer, 0, q->msg_words * 8, c->stream));
+    SOT_HIP(hipMemsetAsync(q->e_peer, 0, q->msg_words * 8, c->stream));
+    SOT_HIP(hipMemcpyAsync(q->d_peer, d_peer, nb, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(q->e_peer, e_peer, nb, hipMemcpyHostToDevice, c->stream));
+    return and_eval_launch(q, layer, party_id, q->d_peer, q->e_peer);
+}
+
+extern "C" int sot_and_circ_layer_eval_peer(sot_and_circ *q, uint32_t layer, uint32_t party_id, sot_and_circ *peer) {
+    if (!q || !peer || layer >= q->n_layers || party_id > 1 || peer->n_layers != q->n_layers ||
+        peer->count[layer] != q->count[layer] || peer->ctx->device != q->ctx->device)
+        return SOT_EINVAL;
+    if (!q->msg_done[layer] || peer->msg_layer != (int64_t)layer) {
+        sot_set_error("and_circ: layer_eval_peer before both parties' layer_msg");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(q->ctx->device));
+    // the peer's message is copied out of its buffers (it may start its next layer at once)
+    const uint64_t nbw = (((uint64_t)q->count[layer] + 63) / 64) * 8;
+    SOT_HIP(hipMemcpyAsync(q->d_peer, peer->d_own, nbw, hipMemcpyDeviceToDevice, q->ctx->stream));
+    SOT_HIP(hipMemcpyAsync(q->e_peer, peer->e_own, nbw, hipMemcpyDeviceToDevice, q->ctx->stream));
+    return and_eval_launch(q, layer, party_id, q->d_peer, q->e_peer);
+}
+
+extern "C" int sot_and_circ_values(sot_and_circ *q, uint8_t *bits_out) {
+    if (!q || !bits_out) return SOT_EINVAL;
+    sot_ctx *c = q->ctx;
+    SOT_HIP(hipSetDevice(c->device));
+    std::vector<uint64_t> w(q->val_words);
+    SOT_HIP(hipMemcpyAsync(w.data(), q->vals, q->val_words * 8, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    auto bit = [&](uint64_t i) { return (uint8_t)((w[i >> 6] >> (i & 63)) & 1); };
+    for (uint32_t i = 0; i < q->n_inputs; i++) bits_out[i] = bit(i);
+    for (uint32_t l = 0; l < q->n_layers; l++)
+        for (uint32_t j = 0; j < q->count[l]; j++) bits_out[q->n_inputs + q->goff[l] + j] = bit(q->base[l] + j);
+    return SOT_OK;
+}
+
+extern "C" uint64_t sot_mt_remaining(const sot_ctx *c) { return c && c->mt_valid ? c->mt_rem : 0; }

@@ -68,6 +68,8 @@ enum sot_kid {
     KID_CONV_INV,
     KID_QC_STORE,
     KID_QC_FINAL,
+    KID_AND_MSG,
+    KID_AND_EVAL,
     KID_COUNT
 };
 extern const char *const SOT_KID_NAMES[KID_COUNT];
@@ -117,6 +119,7 @@ struct sot_ctx {
     // MT bits
     uint64_t *d_mt = nullptr;  // a | b | c words
     bool mt_valid = false;     // set by hash_mt_bits, cleared by the next expand
+    uint64_t mt_rem = 0;       // triples not yet consumed by sot_and_circ_layer_msg (taken from the END of the store)
     void *d_tmp = nullptr;     // download staging
     uint64_t tmp_bytes = 0;
     // profiling

@@ -29,7 +29,9 @@ EXPORTS = [
     "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_random_silent_send",
     "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
-    "sot_qc_transform_row", "sot_qc_log2_capacity",
+    "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
+    "sot_and_circ_set_inputs", "sot_and_circ_layer_msg", "sot_and_circ_layer_eval", "sot_and_circ_layer_eval_peer",
+    "sot_and_circ_values", "sot_mt_remaining",
 ]
 
 
@@ -83,6 +85,17 @@ def load_library():
     L.sot_qc_transform_row.argtypes = [P, P, i32, P]
     L.sot_qc_log2_capacity.argtypes = [P]
     L.sot_qc_log2_capacity.restype = C.c_uint32
+    u32 = C.c_uint32
+    L.sot_and_circ_create.argtypes = [P, u32, u32, u32, P, P, P, C.POINTER(P)]
+    L.sot_and_circ_destroy.argtypes = [P]
+    L.sot_and_circ_destroy.restype = None
+    L.sot_and_circ_set_inputs.argtypes = [P, P]
+    L.sot_and_circ_layer_msg.argtypes = [P, u32, P, P]
+    L.sot_and_circ_layer_eval.argtypes = [P, u32, u32, P, P]
+    L.sot_and_circ_layer_eval_peer.argtypes = [P, u32, u32, P]
+    L.sot_and_circ_values.argtypes = [P, P]
+    L.sot_mt_remaining.argtypes = [P]
+    L.sot_mt_remaining.restype = u64
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or name.startswith("sot_") and fn.restype == C.c_int:

@@ -1,0 +1,157 @@
+"""Host-side mirror of FLUTE's function-dependent setup (crates/gmw/src/protocols/aby2_lut.rs:699-783):
+LutSetupProvider::setup builds a Boolean AND circuit over the private mask bits of every LUT gate's inputs -- one AND
+per subset of size >= 2 of the (sorted) inputs, chained through the smaller subset (setup_data_circ, :321-370) -- and
+evaluates it with BooleanGmw and multiplication triples, one network round per subset size.
+
+The graph walk stays on the host (it is the reference's circuit IR); what this module produces is
+the flat description the device evaluates: per AND gate the two operand ids, per layer the gate count. The AND layers
+themselves (boolean_gmw.rs:40-95, evaluate.rs:5-21) run on the GPU behind sot_and_circ_* with the triples taken from
+the END of the context's device-resident MT store (Executor::execute, executor.rs:139: split_off_last per layer).
+
+Operand order. `lhs & rhs` wires [lhs, rhs] (share_wrapper.rs:165-180) and the executor reads a gate's inputs through
+parent_gates(), which yields them in REVERSE insertion order (base_circuit.rs:122-133, test :644-655); so in
+and::compute_shares(x, y, mt) (boolean_gmw.rs:54-61) x = rhs and y = lhs:
+   [a, b]            -> a & b           -> x = b,          y = a
+   [subset.., last]  -> last & subset   -> x = subset_out, y = last
+Gate order. Gate ids grow in creation order; a layer's interactive gates are sorted by id (base_circuit.rs:481-484);
+an AND over a subset of size k sits in layer k - 2 (its parents are an input and the AND of size k - 1).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .lib import check
+
+
+class SetupCircuit:
+    """Flat form of the setup circuit. Value ids: 0 .. n_inputs-1 are the private-share input bits in the order setup()
+    pushes them to circ_inputs (first use, aby2_lut.rs:725-741); n_inputs + i is AND gate i in CREATION order."""
+
+    def __init__(self, n_inputs, x_src, y_src, depth, lut_outputs):
+        self.n_inputs = n_inputs
+        self.x_src = np.asarray(x_src, dtype=np.uint32)
+        self.y_src = np.asarray(y_src, dtype=np.uint32)
+        self.depth = np.asarray(depth, dtype=np.uint32)  # layer of every gate (0 = subsets of size 2)
+        self.lut_outputs = lut_outputs  # per LUT gate: value ids of its 2^p - p - 1 subset products, powerset order
+        self.n_gates = len(self.x_src)
+        self.n_layers = int(self.depth.max()) + 1 if self.n_gates else 0
+        # execution order = (layer, gate id); value ids are renumbered so that a layer's outputs are contiguous
+        order = np.lexsort((np.arange(self.n_gates), self.depth))
+        self.exec_order = order
+        self.layer_counts = np.bincount(self.depth, minlength=self.n_layers).astype(np.uint32)
+        rank = np.empty(self.n_gates, dtype=np.int64)
+        rank[order] = np.arange(self.n_gates)
+        self._rank = rank
+
+    def exec_id(self, value_id):
+        """creation-order value id -> execution-order value id (inputs unchanged)"""
+        v = np.asarray(value_id, dtype=np.int64)
+        return np.where(v < self.n_inputs, v, self.n_inputs + self._rank[np.maximum(v - self.n_inputs, 0)])
+
+    def exec_arrays(self):
+        xs = self.exec_id(self.x_src[self.exec_order]).astype(np.uint32)
+        ys = self.exec_id(self.y_src[self.exec_order]).astype(np.uint32)
+        return xs, ys
+
+
+def build_setup_circuit(lut_gate_parents):
+    """lut_gate_parents: for every interactive LUT gate, in circuit.interactive_iter() order, the ids of its parent
+    gates (any hashable, e.g. (circuit_id, gate_id)). Follows setup() :717-741 (inputs numbered at first use, the
+    gate's input shares SORTED -- ShareWrapper orders by its output gate id, i.e. by input number) and setup_data_circ
+    :321-358 (powerset without the empty and single-element sets, cache keyed by the subset)."""
+    from itertools import combinations
+    input_of = {}
+    x_src, y_src, depth = [], [], []
+    cache = {}
+    lut_outputs = []
+    n_inputs_total = len({p for parents in lut_gate_parents for p in parents})
+    for parents in lut_gate_parents:
+        ins = []
+        for p in parents:
+            if p not in input_of:
+                input_of[p] = len(input_of)
+            ins.append(input_of[p])
+        ins.sort()
+        outs = []
+        for k in range(2, len(ins) + 1):
+            for sub in combinations(ins, k):
+                if sub not in cache:
+                    gid = n_inputs_total + len(x_src)
+                    if k == 2:
+                        x_src.append(sub[1]), y_src.append(sub[0]), depth.append(0)
+                    else:
+                        x_src.append(cache[sub[:-1]]), y_src.append(sub[-1]), depth.append(k - 2)
+                    cache[sub] = gid
+                outs.append(cache[sub])
+        lut_outputs.append(outs)
+    return SetupCircuit(n_inputs_total, x_src, y_src, depth, lut_outputs)
+
+
+class AndCircuit:
+    """Device evaluator of a SetupCircuit on an Engine (C ABI sot_and_circ_*). Mirrors Executor<BooleanGmw>:
+    per layer compute_msg -> exchange -> evaluate_interactive; MTs come from the end of the engine's MT store."""
+
+    def __init__(self, engine, circ, party_id):
+        self.engine, self.circ, self.party_id = engine, circ, party_id
+        xs, ys = circ.exec_arrays()
+        h = C.c_void_p()
+        lc = np.ascontiguousarray(circ.layer_counts, dtype=np.uint32)
+        check(engine.lib.sot_and_circ_create(engine.h, circ.n_inputs, circ.n_gates, circ.n_layers,
+                                             lc.ctypes.data_as(C.c_void_p), xs.ctypes.data_as(C.c_void_p),
+                                             ys.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.lib.sot_and_circ_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_inputs(self, bits):
+        """bits: the private share of every circuit input (circ_inputs of setup()), one 0/1 per input"""
+        b = np.asarray(bits, dtype=np.uint8)
+        assert b.shape == (self.circ.n_inputs,)
+        w = np.packbits(np.concatenate([b, np.zeros((-len(b)) % 64, np.uint8)]), bitorder="little")
+        check(self.engine.lib.sot_and_circ_set_inputs(self.h, w.ctypes.data_as(C.c_void_p)))
+
+    def layer_msg(self, layer, download=True):
+        """BooleanGmw::compute_msg for one layer -> (d, e) as the bytes of BitVec<u8, Lsb0>::into_vec()"""
+        nb = (int(self.circ.layer_counts[layer]) + 7) // 8
+        if not download:
+            check(self.engine.lib.sot_and_circ_layer_msg(self.h, layer, None, None))
+            return None
+        d = np.zeros(nb, dtype=np.uint8)
+        e = np.zeros(nb, dtype=np.uint8)
+        check(self.engine.lib.sot_and_circ_layer_msg(self.h, layer, d.ctypes.data_as(C.c_void_p),
+                                                     e.ctypes.data_as(C.c_void_p)))
+        return d, e
+
+    def layer_eval(self, layer, peer_d, peer_e):
+        """BooleanGmw::evaluate_interactive with the peer's message"""
+        pd = np.ascontiguousarray(peer_d, dtype=np.uint8)
+        pe = np.ascontiguousarray(peer_e, dtype=np.uint8)
+        check(self.engine.lib.sot_and_circ_layer_eval(self.h, layer, self.party_id, pd.ctypes.data_as(C.c_void_p),
+                                                      pe.ctypes.data_as(C.c_void_p)))
+
+    def layer_eval_from(self, layer, peer):
+        """same, the peer's message taken device-to-device from another AndCircuit on the same GPU (benchmarks)"""
+        check(self.engine.lib.sot_and_circ_layer_eval_peer(self.h, layer, self.party_id, peer.h))
+
+    def values(self):
+        """all value bits (inputs, then AND outputs) in CREATION order, one 0/1 per value"""
+        n = self.circ.n_inputs + self.circ.n_gates
+        w = np.zeros((n + 63) // 64 + self.circ.n_layers + 1, dtype=np.uint64)
+        bits = np.zeros(n, dtype=np.uint8)
+        check(self.engine.lib.sot_and_circ_values(self.h, bits.ctypes.data_as(C.c_void_p)))
+        out = np.empty(n, dtype=np.uint8)
+        out[:self.circ.n_inputs] = bits[:self.circ.n_inputs]
+        out[self.circ.n_inputs + self.circ.exec_order] = bits[self.circ.n_inputs:]
+        del w
+        return out
+
+    def lut_eval_shares(self):
+        """LutEvalShares of every LUT gate (aby2_lut.rs:761-781): its subset-product shares in powerset order"""
+        v = self.values()
+        return [v[np.asarray(o, dtype=np.int64)] for o in self.circ.lut_outputs]

@@ -122,6 +122,35 @@ int sot_mt_bits(sot_ctx *ctx, const void *delta, uint64_t *a_out, uint64_t *b_ou
  * RCCL all-gather that reassembles its MT store from the per-GPU instances. */
 int sot_mt_bits_to_device(sot_ctx *ctx, void *dst_device, uint64_t dst_bytes);
 
+/* ---- FLUTE function-dependent setup: AND layers over the expanded triples ------------------ */
+/* LutSetupProvider::setup (gmw/src/protocols/aby2_lut.rs:699-783) evaluates, with BooleanGmw and multiplication
+ * triples, a circuit that has one AND per subset (size >= 2) of every LUT gate's private input masks
+ * (setup_data_circ, :321-370). The circuit is built by the host (graph walk; flute_amd/lut_setup.py mirrors it) and
+ * handed over flat: value ids 0 .. n_inputs-1 are the input bits, n_inputs + g is AND gate g; the gates are listed
+ * in EXECUTION order = sorted by (layer, gate id), the order inside a layer of the reference (base_circuit.rs:481-484);
+ * layer_counts[l] gates belong to layer l; x_src / y_src are the value ids and::compute_shares(x, y, mt) receives
+ * (boolean_gmw.rs:54-61; note parent_gates() reverses the wiring order, base_circuit.rs:122-133). Triples are taken
+ * from the END of the context's MT store in gate order (Executor::execute, executor.rs:139: split_off_last). */
+typedef struct sot_and_circ sot_and_circ;
+int sot_and_circ_create(sot_ctx *ctx, uint32_t n_inputs, uint32_t n_gates, uint32_t n_layers,
+                        const uint32_t *layer_counts, const uint32_t *x_src, const uint32_t *y_src, sot_and_circ **out);
+void sot_and_circ_destroy(sot_and_circ *circ);
+/* circ_inputs of setup() (aby2_lut.rs:710,727-733): this party's private share bits, Lsb0 in u64 words */
+int sot_and_circ_set_inputs(sot_and_circ *circ, const uint64_t *input_words);
+/* BooleanGmw::compute_msg for one layer (boolean_gmw.rs:40-67): Msg::AndLayer { d, e } as the ceil(count/8) bytes
+ * of BitVec<u8, Lsb0>::into_vec() (dead bits zero); NULL leaves the message on the device. Consumes the triples. */
+int sot_and_circ_layer_msg(sot_and_circ *circ, uint32_t layer, uint8_t *d_out, uint8_t *e_out);
+/* BooleanGmw::evaluate_interactive (boolean_gmw.rs:69-95, evaluate.rs:12-21) with the peer's message */
+int sot_and_circ_layer_eval(sot_and_circ *circ, uint32_t layer, uint32_t party_id, const uint8_t *d_peer,
+                            const uint8_t *e_peer);
+/* same, the peer's message read device-to-device from the peer's circuit on the SAME GPU (in-process two-party
+ * runs: tests, benchmarks; the reference's analogue is mpc_channel::in_memory) */
+int sot_and_circ_layer_eval_peer(sot_and_circ *circ, uint32_t layer, uint32_t party_id, sot_and_circ *peer);
+/* gate_outputs()[0] of the executor (aby2_lut.rs:761): one byte 0/1 per value, inputs then gates in execution order */
+int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
+/* triples left in the context's store (MulTriples::len after the split_off_last calls so far) */
+uint64_t sot_mt_remaining(const sot_ctx *ctx);
+
 /* ---- whole-direction pipelines (random_silent_send / random_silent_receive) --------------- */
 /* silent_ot/mod.rs:193-211. msgs_out may be NULL (results stay in HBM). */
 int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed,

@@ -1,0 +1,130 @@
+"""GPU parity of the FLUTE setup AND layers (sot_and_circ_*) against oracle/lut_setup_oracle.py: messages
+and every gate value bit for bit, with the multiplication triples of two crossed silent-OT instances."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flute_amd
+    if flute_amd.device_count() < 1:
+        pytest.fail("no gfx950 device: GPU tests need the HIP path")
+    return flute_amd
+
+
+def _two_providers(fa, n, T, seed):
+    e0, e1 = fa.Engine(n), fa.Engine(n)
+    rng = np.random.default_rng(seed)
+    x = fa.fake_base(e0.conf, rng)
+    y = fa.fake_base(e0.conf, rng)
+    d0, d1, s0, s1 = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    mts = []
+    tg0 = e0.sender_expand(x[0], d0, s0, T)
+    e0.qc_encode(0)
+    tg1 = e1.sender_expand(y[0], d1, s1, T)
+    e1.qc_encode(0)
+    e0.receiver_expand(y[1], y[2], *tg1)
+    e0.qc_encode(1, e0.points(y[2]))
+    e1.receiver_expand(x[1], x[2], *tg0)
+    e1.qc_encode(1, e1.points(x[2]))
+    for e, d in ((e0, d0), (e1, d1)):
+        a, b, c = e.mt_bits(d)
+        mts.append(tuple(fa.MulTriples._bits(w, n) for w in (a, b, c)))
+    return e0, e1, mts
+
+
+CIRCUITS = {
+    "sbox8_x8": [((i, j) for j in range(8)) for i in range(8) for _ in range(8)],  # 8 instances x 8 LUT gates
+    "overlap": [(0, 1, 2), (2, 1, 3), (0, 1, 2, 3), (5, 4)],
+    "ragged": [(3, 9), (1, 2, 3, 4, 5), (7,), (9, 3, 1)],  # a 1-input LUT contributes nothing
+}
+
+
+@pytest.mark.parametrize("name", list(CIRCUITS))
+def test_and_layers_match_oracle(fa, name):
+    from oracle import lut_setup_oracle as lo
+    luts = [tuple(l) for l in CIRCUITS[name]]
+    n = 3000
+    e0, e1, mts = _two_providers(fa, n, 2, 41)
+    try:
+        circ = fa.build_setup_circuit(luts)
+        rng = np.random.default_rng(8)
+        in0 = rng.integers(0, 2, circ.n_inputs, dtype=np.uint8)
+        in1 = rng.integers(0, 2, circ.n_inputs, dtype=np.uint8)
+        g, _, out_ids, p0, p1, tr = (lambda r: (r[0], None, r[1], r[2], r[3], r[4]))(
+            lo.run_two_party(luts, in0, in1, mts[0], mts[1]))
+        c0, c1 = fa.AndCircuit(e0, circ, 0), fa.AndCircuit(e1, circ, 1)
+        c0.set_inputs(in0)
+        c1.set_inputs(in1)
+        assert len(tr) == circ.n_layers
+        used = 0
+        for layer in range(circ.n_layers):
+            m0, m1 = c0.layer_msg(layer), c1.layer_msg(layer)
+            (od0, oe0), (od1, oe1), _ = tr[layer]
+            assert np.array_equal(m0[0], od0) and np.array_equal(m0[1], oe0), "party 0 message differs"
+            assert np.array_equal(m1[0], od1) and np.array_equal(m1[1], oe1), "party 1 message differs"
+            c0.layer_eval(layer, *m1)
+            c1.layer_eval(layer, *m0)
+            used += int(circ.layer_counts[layer])
+            assert e0.lib.sot_mt_remaining(e0.h) == n - used
+        and_ids = [i for i, k in enumerate(g.kind) if k == "and"]
+        in_ids = [i for i, k in enumerate(g.kind) if k == "in"]
+        for c, p in ((c0, p0), (c1, p1)):
+            v = c.values()
+            assert np.array_equal(v[:circ.n_inputs], p.out[in_ids])
+            assert np.array_equal(v[circ.n_inputs:], p.out[and_ids]), "gate values differ from the oracle"
+        # LutEvalShares in powerset order + the protocol property
+        lam = in0 ^ in1
+        s0, s1 = c0.lut_eval_shares(), c1.lut_eval_shares()
+        for parents, a, b, outs in zip(luts, s0, s1, circ.lut_outputs):
+            assert len(a) == 2 ** len(parents) - len(parents) - 1
+        v0, v1 = c0.values(), c1.values()
+        prod = v0 ^ v1
+        for j in range(circ.n_gates):
+            x, y = int(circ.x_src[j]), int(circ.y_src[j])
+            assert prod[circ.n_inputs + j] == (prod[x] & prod[y])
+        assert np.array_equal(prod[:circ.n_inputs], lam)
+        # an out-of-order call and running out of triples are errors, not crashes
+        from flute_amd.lib import SotError
+        with pytest.raises(SotError):
+            c0.layer_eval(0, np.zeros(1, np.uint8), np.zeros(1, np.uint8))
+        c0.close()
+        c1.close()
+    finally:
+        e0.close()
+        e1.close()
+
+
+def test_device_to_device_exchange_and_exhaustion(fa):
+    """layer_eval_peer (both parties on one GPU) gives the same values as the host exchange; a layer that needs more
+    triples than the store holds is refused."""
+    from flute_amd.lib import SotError
+    luts = [tuple((i, j) for j in range(6)) for i in range(40)]  # 40 x 57 = 2280 ANDs
+    n = 3000
+    e0, e1, _ = _two_providers(fa, n, 1, 5)
+    try:
+        circ = fa.build_setup_circuit(luts)
+        rng = np.random.default_rng(1)
+        ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+        cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((e0, e1))]
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        for layer in range(circ.n_layers):
+            cs[0].layer_msg(layer, download=False)
+            cs[1].layer_msg(layer, download=False)
+            cs[0].layer_eval_from(layer, cs[1])
+            cs[1].layer_eval_from(layer, cs[0])
+        prod = cs[0].values() ^ cs[1].values()
+        for j in range(circ.n_gates):
+            assert prod[circ.n_inputs + j] == (prod[int(circ.x_src[j])] & prod[int(circ.y_src[j])])
+        assert e0.lib.sot_mt_remaining(e0.h) == n - circ.n_gates
+        # 720 triples left: a second run of layer 0 (600 gates) fits, layer 1 (800) does not
+        cs[0].set_inputs(ins[0])
+        cs[0].layer_msg(0, download=False)
+        with pytest.raises(SotError):
+            cs[0].layer_msg(1, download=False)
+    finally:
+        e0.close()
+        e1.close()
