@@ -65,6 +65,61 @@ def cpu_baseline(log2n_sample, T):
     }
 
 
+def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, log2b, reps):
+    """FLUTE function-dependent setup (aby2_lut.rs:699-783) for 2^log2b instances of to_eval/sbox8.lut (one grouped
+    8-input LUT with 8 outputs = 8 LUT gates, 247 AND gates in 7 layers per instance) on the triples just expanded:
+    both parties' AND layers run on this GPU (party 1 = a second engine holding the crossed OT instances), messages
+    exchanged device to device. Returns the `lut_setup` object of the bench line."""
+    n = eng.conf.n
+    B = 1 << log2b
+    eng1 = fa.Engine(n, device=eng.device)
+    try:
+        eng1.sender_expand(y[0], delta_peer, seed_peer, threads)
+        eng1.qc_encode(0)
+        eng1.receiver_expand(x[1], x[2], *tg_x)
+        eng1.qc_encode(1, eng1.points(x[2]))
+        # batched circuit in circuit.interactive_iter() order: per instance (sub-circuit) its 8 LUT gates, all over the
+        # same 8 parents -> 247 ANDs per instance through the subset cache
+        t0 = time.perf_counter()
+        circ = fa.replicate_setup_circuit(fa.build_setup_circuit([tuple(range(8))] * 8), B)
+        t_build = time.perf_counter() - t0
+        assert circ.n_gates == 247 * B <= n
+        rng = np.random.default_rng(99)
+        ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+        cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((eng, eng1))]
+        total = 0.0
+        for rep in range(reps + 1):
+            eng.mt_bits(delta, download=False)  # refill the stores (same triples again: timing only)
+            eng1.mt_bits(delta_peer, download=False)
+            for c, i in zip(cs, ins):
+                c.set_inputs(i)
+            eng.sync(), eng1.sync()
+            t0 = time.perf_counter()
+            for layer in range(circ.n_layers):
+                cs[0].layer_msg(layer, download=False)
+                cs[1].layer_msg(layer, download=False)
+                cs[0].layer_eval_from(layer, cs[1])
+                cs[1].layer_eval_from(layer, cs[0])
+            eng.sync(), eng1.sync()
+            if rep:
+                total += time.perf_counter() - t0
+        v0, v1 = cs[0].values(), cs[1].values()
+        prod = v0 ^ v1
+        ok = bool(np.array_equal(prod[circ.n_inputs:], prod[circ.x_src] & prod[circ.y_src]) and
+                  np.array_equal(prod[:circ.n_inputs], ins[0] ^ ins[1]))
+        for c in cs:
+            c.close()
+        dt = total / reps
+        return {"metric": "FLUTE LUT setup, sbox8.lut instances/s (both parties' AND layers on one GPU)",
+                "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "and_gates_per_s": 247 * B / dt,
+                "batch": B, "ms_per_batch": dt * 1e3, "layers": int(circ.n_layers), "mts_consumed": int(circ.n_gates),
+                "subset_products_correct": ok, "host_circuit_build_s": t_build,
+                "note": "7 layers x (2 messages + 2 evaluations), every call synchronous; triples come from the device "
+                        "MT store of the expansion above; host-side circuit build (graph walk) not in the timed region"}
+    finally:
+        eng1.close()
+
+
 def load_pmc():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
     the profiler on itself; tools_profile.sh + tools_prof_summary.py produce profiles/pmc_latest.json)."""
@@ -90,6 +145,7 @@ def main():
                     help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsals on a 1-GPU box)")
+    ap.add_argument("--lut-log2b", type=int, default=16, help="FLUTE setup section: 2^b sbox8 instances (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
@@ -120,13 +176,14 @@ def main():
     # once, outside the timed region, by running the peer's sender expansion on this engine
     tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads)
     pts = eng.points(y[2])
+    tg_x = [None]
 
     # N > 1: every step ends with the one exchange of the path, the all-gather (RCCL over xGMI) that leaves the
     # party's whole MT store -- a | b | c of every rank's instance, 6 MiB per rank -- on every GPU
     gather = {"on": world > 1 and not args.no_gather, "buf": None, "note": None}
 
     def step():
-        eng.sender_expand(x[0], delta, seed, args.threads)
+        tg_x[0] = eng.sender_expand(x[0], delta, seed, args.threads)
         eng.qc_encode(0)
         eng.receiver_expand(y[1], y[2], *tg_y)
         eng.qc_encode(1, pts)
@@ -227,6 +284,12 @@ def main():
                 out["roofline"]["traffic_note"] = pmc.get("note")
             out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(),
                                                                                 key=lambda kv: -kv[1][0])}
+        if args.lut_log2b and world == 1 and 247 << args.lut_log2b <= n:
+            try:
+                out["lut_setup"] = lut_setup_bench(fa, eng, x, y, tg_x[0], delta, delta_peer, seed_peer, args.threads,
+                                                   args.lut_log2b, 5)
+            except Exception as e:  # a secondary section: never takes the headline line down
+                out["lut_setup"] = {"value": None, "note": "failed: %r" % (e,)}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, args.threads)

@@ -64,8 +64,13 @@ def build_setup_circuit(lut_gate_parents):
     x_src, y_src, depth = [], [], []
     cache = {}
     lut_outputs = []
+    lut_gate_parents = [tuple(p) for p in lut_gate_parents]
     n_inputs_total = len({p for parents in lut_gate_parents for p in parents})
+    last_parents, last_outs = None, None
     for parents in lut_gate_parents:
+        if parents == last_parents:  # same input set as the previous LUT gate: every subset is a cache hit
+            lut_outputs.append(list(last_outs))
+            continue
         ins = []
         for p in parents:
             if p not in input_of:
@@ -84,7 +89,34 @@ def build_setup_circuit(lut_gate_parents):
                     cache[sub] = gid
                 outs.append(cache[sub])
         lut_outputs.append(outs)
+        last_parents, last_outs = parents, outs
     return SetupCircuit(n_inputs_total, x_src, y_src, depth, lut_outputs)
+
+
+def replicate_setup_circuit(template, batch):
+    """The setup circuit of `batch` sub-circuit instances of a ONE-LAYER LUT circuit (e.g. to_eval/sbox8.lut, #DEPTH 1),
+    as flute_benchmark builds it (bench.rs:367-384): interactive_iter() then visits instance 0's LUT gates, instance
+    1's, ... so the creation order is instance-major and build_setup_circuit(parents of all instances) equals the
+    template with its ids shifted per instance -- built here with numpy instead of a Python loop per gate.
+    (A LUT circuit with several layers is visited layer-major; use build_setup_circuit for it.)"""
+    t = template
+    ni, ng = t.n_inputs, t.n_gates
+    inst = np.arange(batch, dtype=np.int64)[:, None]
+
+    def shift(src):
+        src = src.astype(np.int64)[None, :]
+        return np.where(src < ni, src + inst * ni, batch * ni + (src - ni) + inst * ng).reshape(-1)
+
+    outs = []
+    if t.lut_outputs:
+        tmpl = [np.asarray(o, dtype=np.int64) for o in t.lut_outputs]
+        if len({len(o) for o in tmpl}) == 1:  # same fan-in everywhere: one broadcast, rows are views
+            arr = (batch * ni + (np.stack(tmpl) - ni))[None, :, :] + (inst * ng)[:, :, None]
+            outs = list(arr.reshape(-1, arr.shape[-1]))
+        else:
+            for i in range(batch):
+                outs.extend(batch * ni + (o - ni) + i * ng for o in tmpl)
+    return SetupCircuit(batch * ni, shift(t.x_src), shift(t.y_src), np.tile(t.depth, batch), outs)
 
 
 class AndCircuit:

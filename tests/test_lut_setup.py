@@ -88,3 +88,15 @@ def test_oracle_subset_product_property(name):
         assert len(subs) == len(outs)
         for s, o in zip(subs, outs):
             assert (p0.out[o] ^ p1.out[o]) == np.bitwise_and.reduce(lam[list(s)])
+
+
+def test_replicated_template_equals_generic_builder():
+    from flute_amd.lut_setup import replicate_setup_circuit
+    B = 5
+    tmpl = build_setup_circuit([tuple(range(8))] * 8)
+    full = build_setup_circuit([tuple((i, j) for j in range(8)) for i in range(B) for _ in range(8)])
+    rep = replicate_setup_circuit(tmpl, B)
+    assert rep.n_inputs == full.n_inputs and rep.n_gates == full.n_gates
+    for name in ("x_src", "y_src", "depth", "exec_order", "layer_counts"):
+        assert np.array_equal(getattr(rep, name), getattr(full, name)), name
+    assert all(np.array_equal(a, b) for a, b in zip(rep.lut_outputs, full.lut_outputs))
