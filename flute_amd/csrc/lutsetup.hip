@@ -20,7 +20,8 @@
 
 extern "C" void sot_and_circ_destroy(sot_and_circ *q);
 struct sot_and_circ {
-    sot_ctx *ctx = nullptr;
+    sot_ctx *ctx = nullptr;  // must outlive the circuit, except for sot_and_circ_destroy
+    int device = 0;
     uint32_t n_inputs = 0, n_gates = 0, n_layers = 0;
     std::vector<uint32_t> count, goff;  // per layer: gates, index of its first gate (execution order)
     std::vector<uint64_t> base;         // per layer: first value bit (64-aligned)
@@ -95,6 +96,7 @@ extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gat
     }
     sot_and_circ *q = new sot_and_circ();
     q->ctx = c;
+    q->device = c->device;
     q->n_inputs = n_inputs, q->n_gates = n_gates, q->n_layers = n_layers;
     q->count.assign(layer_counts, layer_counts + n_layers);
     q->goff.resize(n_layers), q->base.resize(n_layers), q->mt0.assign(n_layers, 0), q->msg_done.assign(n_layers, 0);
@@ -160,7 +162,7 @@ extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gat
 
 extern "C" void sot_and_circ_destroy(sot_and_circ *q) {
     if (!q) return;
-    if (q->ctx) (void)hipSetDevice(q->ctx->device);
+    (void)hipSetDevice(q->device);
     void *ptrs[] = {q->xpos, q->ypos, q->vals, q->d_own, q->e_own, q->d_peer, q->e_peer};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -841,23 +841,23 @@ __device__ __forceinline__ uint32_t tile_word(const tile_desc &d, uint32_t t) {
 #define TL_WAVES (TL_THREADS / 64)
 
 // all loads of a wave are issued before the first LDS store (2^NB / 16 granules in flight per wave)
-template <int NB>
+template <int NB, int WAVES = TL_WAVES>
 __device__ __forceinline__ void tile_load(uint32_t *lds, const uint32_t *__restrict__ Z, const tile_desc &d,
                                           uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
-    constexpr int PER = (1 << NB) / TL_WAVES;
+    constexpr int PER = (1 << NB) / WAVES;
     const uint32_t nslots = 1u << d.nb;
     const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
     uint32_t v[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const uint32_t s = wave + TL_WAVES * i;
+        const uint32_t s = wave + WAVES * i;
         v[i] = 0;
         if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u)))
-            v[i] = g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS];
+            v[i] = g[(uint64_t)tile_word(d, WAVES * i) * ROWS];
     }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const uint32_t s = wave + TL_WAVES * i;
+        const uint32_t s = wave + WAVES * i;
         if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
     }
 }
@@ -895,16 +895,16 @@ __device__ __forceinline__ void tile_put(uint32_t *lds, typename tile_regs<(1 <<
         if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
     }
 }
-template <int NB>
+template <int NB, int WAVES = TL_WAVES>
 __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__restrict__ Z, const tile_desc &d,
                                            uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
-    constexpr int PER = (1 << NB) / TL_WAVES;
+    constexpr int PER = (1 << NB) / WAVES;
     const uint32_t nslots = 1u << d.nb;
     uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const uint32_t s = wave + TL_WAVES * i;
-        if (s < nslots) g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS] = lds[s * TL_ROWS + lane];
+        const uint32_t s = wave + WAVES * i;
+        if (s < nslots) g[(uint64_t)tile_word(d, WAVES * i) * ROWS] = lds[s * TL_ROWS + lane];
     }
 }
 
@@ -1511,11 +1511,14 @@ __device__ __forceinline__ void low_word_levels(uint32_t *lds, const tile_desc &
 // K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
 // pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
 // Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
-template <int MODE>
-__global__ void __launch_bounds__(TL_THREADS)
+// NVW = value words per tile = 2^(d.nb - 5) = waves per workgroup (one value word per wave in the intra-word part, one
+// work item per wave in the word levels): 16 for m >= 25, fewer for the small transforms (m = 21: a single wave).
+template <int MODE, int NVW>
+__global__ void __launch_bounds__(64 * NVW)
     k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ LM,
               const uint32_t *__restrict__ Amat) {
-    __shared__ uint32_t lds[512 * TL_ROWS];
+    constexpr int NBK = NVW == 16 ? 9 : NVW == 8 ? 8 : NVW == 4 ? 7 : NVW == 2 ? 6 : 5;
+    __shared__ uint32_t lds[32 * NVW * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t rh = blockIdx.x & 1;
@@ -1527,10 +1530,10 @@ __global__ void __launch_bounds__(TL_THREADS)
     uint32_t pf = 0;
     if (wave < nvw && !(MODE == 1 && QC_LOWMASK_LDS))
         mask_prefetch(pf, LM + ((uint64_t)o * nvw + wave) * (5 * 512) + 3 * 512 + lane * 16);  // levels 3, 4
-    tile_load<9>(lds, Z, d, base_w, rh, wave, lane);
+    tile_load<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
     if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
-    for (uint32_t vi = wave; vi < nvw; vi += TL_WAVES) {
+    for (uint32_t vi = wave; vi < nvw; vi += NVW) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
         const uint64_t vw = (uint64_t)o * nvw + vi;  // wave-uniform
         const uint32_t *L = LM + vw * (5 * 512);
@@ -1620,7 +1623,19 @@ __global__ void __launch_bounds__(TL_THREADS)
     }
     __syncthreads();
     if (MODE == 1 && !(QC_EXP & 1)) low_word_levels<true>(lds, d, base_w, TW, wave, lane);
-    tile_store<9>(lds, Z, d, base_w, rh, wave, lane);
+    tile_store<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
+}
+
+template <int MODE>
+static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
+    const dim3 g((1u << (d.m - 5 - d.nb)) * 2);
+    switch (d.nb) {
+        case 5: hipLaunchKernelGGL((k_fft_low<MODE, 1>), g, dim3(64), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        case 6: hipLaunchKernelGGL((k_fft_low<MODE, 2>), g, dim3(128), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        case 7: hipLaunchKernelGGL((k_fft_low<MODE, 4>), g, dim3(256), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        case 8: hipLaunchKernelGGL((k_fft_low<MODE, 8>), g, dim3(512), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        default: hipLaunchKernelGGL((k_fft_low<MODE, 16>), g, dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+    }
 }
 
 // LM[((value word * 5 + i) * 16 + j) * 32 + k]: the packed twiddle masks of intra-word level i (see low_level)
@@ -2227,8 +2242,7 @@ static int upload_a_and_transform(sot_ctx *c) {
     fft_forward_upper(c, zb[cur], plan);
     hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * 512, 256)), dim3(256), 0, c->stream, plan.low,
                        g.nw / 32, c->TW, c->LM);
-    hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, zb[cur], plan.low, c->TW,
-                       c->LM, (const uint32_t *)nullptr);
+    launch_low<0>(c, zb[cur], plan.low);
     hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * 1024, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
                        g.nw / 32, c->Amat);
     SOT_HIP(hipGetLastError());
@@ -2321,8 +2335,9 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
-    SOT_LAUNCH(c, KID_FFT_LOW_MUL, k_fft_low<1>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), zb[cur], plan.low, c->TW,
-               c->LM, c->Amat);
+    if (c->prof) prof_begin(c, KID_FFT_LOW_MUL);
+    launch_low<1>(c, zb[cur], plan.low);
+    if (c->prof) prof_end(c, KID_FFT_LOW_MUL);
     fft_inverse_upper(c, zb[cur], plan);
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     if (g.tail > FN_TAILMAX) {
@@ -2356,8 +2371,7 @@ int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_ou
     uint32_t *Z = zb[cur];
     if (stage >= 1) fft_forward_upper(c, Z, plan, stage);
     if (stage >= 4)
-        hipLaunchKernelGGL(k_fft_low<0>, dim3(tile_grid(plan.low)), dim3(TL_THREADS), 0, c->stream, Z, plan.low, c->TW,
-                           c->LM, (const uint32_t *)nullptr);
+        launch_low<0>(c, Z, plan.low);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipMemcpy2DAsync(row_out, 4, Z, ROWS * 4, 4, g.nw, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));

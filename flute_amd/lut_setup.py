@@ -132,6 +132,7 @@ class AndCircuit:
                                              lc.ctypes.data_as(C.c_void_p), xs.ctypes.data_as(C.c_void_p),
                                              ys.ctypes.data_as(C.c_void_p), C.byref(h)))
         self.h = h
+        engine._circuits.append(self)  # Engine.close() destroys its circuits before the context
 
     def close(self):
         if getattr(self, "h", None):

@@ -105,8 +105,12 @@ class Engine:
         check(self.lib.sot_ctx_conf(self.h, C.byref(c)))
         self.conf = QuasiCyclicConf(c)
         self.device = device
+        self._circuits = []  # AndCircuit objects evaluated on this context (lut_setup.py)
 
     def close(self):
+        for circ in getattr(self, "_circuits", []):
+            circ.close()
+        self._circuits = []
         if getattr(self, "h", None):
             self.lib.sot_ctx_destroy(self.h)
             self.h = None
