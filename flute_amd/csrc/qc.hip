@@ -772,6 +772,86 @@ __global__ void __launch_bounds__(CT_THREADS)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2w: the whole-unit phases (chunk and pw multiples of a 2^16 unit) when the top butterfly pass cannot host them
+// (m >= 26: more unit-index bits than its tile has). They only XOR granules that sit at the same offset of different
+// units, so a tile = ALL 2^nub units x one word offset x 16 rows (64 B per unit, 128 KiB at nub = 11) takes every
+// phase in one HBM round trip, in place; before, each phase was a pass of k_conv_phase over the whole array (85 ms
+// of a 155 ms step at n = 2^26). Persistent with next-tile prefetch like k_conv_unit.
+struct wu_phases {
+    uint32_t nub;  // log2(units)
+    uint32_t nph;
+    uint8_t lchunk[32], lpw[32];  // log2 of chunk and pw in units; half = chunk / 2
+};
+__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t nub, uint32_t tile) {
+    const uint32_t o = tile >> 3, rg = tile & 7;
+    const uint32_t items = 4u << nub;
+    const uint32_t *g = D + (uint64_t)o * ROWS + rg * CT_ROWS;
+    auto ld = [&](uint32_t it) {
+        u4 v = {0, 0, 0, 0};
+        if (it < items) v = ld_u4(g + (uint64_t)(it >> 2) * 2048 * ROWS + 4 * (it & 3));
+        return v;
+    };
+    cu_regs x;
+    const uint32_t i = threadIdx.x;
+    x.a = ld(i), x.b = ld(i + CT_THREADS), x.c = ld(i + 2 * CT_THREADS), x.d = ld(i + 3 * CT_THREADS);
+    x.e = ld(i + 4 * CT_THREADS), x.f = ld(i + 5 * CT_THREADS), x.g = ld(i + 6 * CT_THREADS), x.h = ld(i + 7 * CT_THREADS);
+    return x;
+}
+__global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__restrict__ D, wu_phases ph, int inverse) {
+    __shared__ u4 lds[8192];  // [unit][quad]
+    const uint32_t ntiles = 2048 * 8, items = 4u << ph.nub;
+    uint32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    cu_regs nx = wu_fetch(D, ph.nub, t);
+#pragma unroll 1
+    for (; t < ntiles; t += gridDim.x) {
+        {
+            const uint32_t i = threadIdx.x;
+            lds[i] = nx.a, lds[i + CT_THREADS] = nx.b, lds[i + 2 * CT_THREADS] = nx.c, lds[i + 3 * CT_THREADS] = nx.d;
+            lds[i + 4 * CT_THREADS] = nx.e, lds[i + 5 * CT_THREADS] = nx.f, lds[i + 6 * CT_THREADS] = nx.g;
+            lds[i + 7 * CT_THREADS] = nx.h;
+        }
+        __syncthreads();
+        nx = wu_fetch(D, ph.nub, t + gridDim.x < ntiles ? t + gridDim.x : t);
+        for (uint32_t q = 0; q < ph.nph; q++) {
+            const uint32_t pi = inverse ? ph.nph - 1 - q : q;
+            const uint32_t lchunk = ph.lchunk[pi], lpw = ph.lpw[pi];
+            const uint32_t half = 1u << (lchunk - 1), pw = 1u << lpw, Dd = half - pw;
+            for (int step = 0; step < 2; step++) {
+                const bool fold = inverse ? step == 1 : step == 0;  // forward: fold then shift; inverse: shift then fold
+                if (fold) {
+                    // H[j] ^= H[j + D], j < pw, in every chunk
+                    const uint32_t n_it = (1u << (ph.nub - lchunk + lpw)) * 4;
+                    for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
+                        const uint32_t r = it & 3, w = it >> 2, c = w >> lpw, j = w & (pw - 1);
+                        const uint32_t dst = (c << lchunk) + half + j;
+                        lds[dst * 4 + r] ^= lds[(dst + Dd) * 4 + r];
+                    }
+                } else {
+                    // lo[pw + j] ^= H[j], j < D: enumerate j over [0, half) and skip j >= D
+                    const uint32_t n_it = (1u << (ph.nub - 1)) * 4;
+                    for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
+                        const uint32_t r = it & 3, w = it >> 2, c = w >> (lchunk - 1), j = w & (half - 1);
+                        if (j < Dd) {
+                            const uint32_t base = c << lchunk;
+                            lds[(base + pw + j) * 4 + r] ^= lds[(base + half + j) * 4 + r];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        {
+            const uint32_t o = t >> 3, rg = t & 7;
+            uint32_t *g = D + (uint64_t)o * ROWS + rg * CT_ROWS;
+            for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS)
+                *(u4 *)(g + (uint64_t)(it >> 2) * 2048 * ROWS + 4 * (it & 3)) = lds[it];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // twiddle matrices. TW[tbl][e][k] = row k (bit j set <=> output coordinate k takes input coordinate j) of
 // "multiply by point(e << 8 tbl)", e < 256, tbl < 4; TWC[tbl][e] = that point. point() is GF(2)-linear, so the
 // rows / the element of any index q are the XOR over tbl of the entries of q's bytes.
@@ -1950,6 +2030,24 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
                    nc, inverse ? 1 : 0, (uint32_t)g);
         cur ^= 1;
     };
+    // whole-unit phases outside the top pass: one in-place tile kernel when all units of an offset fit LDS
+    const uint32_t nub = ell_elems > 16 ? ell_elems - 16 : 0;
+    auto whole_units = [&]() {
+        if (units.empty()) return;
+        if (nub < 8 || nub > 11 || units.size() > 32 || getenv("SOT_NO_WU")) {
+            generic(units);
+            return;
+        }
+        wu_phases w;
+        memset(&w, 0, sizeof w);
+        w.nub = nub;
+        for (auto &p : units) {
+            w.lchunk[w.nph] = (uint8_t)(ilog2(p.chunk) - 16);
+            w.lpw[w.nph] = (uint8_t)(ilog2(p.pw) - 16);
+            w.nph++;
+        }
+        SOT_LAUNCH(c, kid, k_conv_wholeunits, dim3(c->num_cus), dim3(CT_THREADS), bufs[cur], w, inverse ? 1 : 0);
+    };
     if (!inverse) {
         if (fusedT) {
             if (haveA) run_taylor(tA, gA, ncA);
@@ -1957,7 +2055,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         } else {
             generic(taylor);
         }
-        if (!units_in_top) generic(units);
+        if (!units_in_top) whole_units();
         if (fused && tb == 16)
             SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_fwd, tgrid);
         else if (small.n)
@@ -1967,7 +2065,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
             SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_inv, tgrid);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
-        if (!units_in_top) generic(units);
+        if (!units_in_top) whole_units();
         if (fusedT) {
             run_taylor(tB, gB, ncB);
             if (haveA) run_taylor(tA, gA, ncA);
