@@ -143,6 +143,87 @@ __global__ void __launch_bounds__(GGM_BLOCK)
     }
 }
 
+__device__ __forceinline__ uint64_t active_path(const uint8_t *cb, uint32_t depth);
+
+// ------------------------------------------------------------------------------------------------
+// The first levels of every tree, staged in LDS: one workgroup per set (8 trees) expands levels d0 .. d1-1 without
+// touching HBM in between -- level l (8 * 2^l Blocks) ping-pongs between two LDS buffers (even l in A, odd l in B),
+// only level d1 (<= 9: 4096 Blocks) and the per-level sums are written out. The receiver's repair of the inactive
+// child (pprf.rs:456-467, k_recv_fix) happens in LDS between two levels; the repair of level d1 itself is left to
+// k_recv_fix. Replaces up to 9 launches of k_ggm_level (+ 8 of k_recv_fix) that were launch-, not AES-bound.
+#define GGM_TOP_THREADS 1024
+#define GGM_TOP_MAXLVL 9
+template <bool RECV>
+__global__ void __launch_bounds__(GGM_TOP_THREADS)
+    k_ggm_top(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t d0, uint32_t d1, uint32_t nsets,
+              blk_t *__restrict__ sums /* [level][set][2][8] */, const blk_t *__restrict__ base,
+              const uint8_t *__restrict__ choices, const blk_t *__restrict__ tg_sums, uint32_t depth) {
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
+    __shared__ blk_t bufA[2048], bufB[1024];
+    __shared__ blk_t red[GGM_TOP_THREADS / 64][2][8];
+    __shared__ blk_t lsum[2][8];
+    aes_lds_fill(te);
+    const uint32_t set = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const uint32_t n0 = 8u << d0;
+        blk_t *b0 = (d0 & 1) ? bufB : bufA;
+        for (uint32_t i = threadIdx.x; i < n0; i += GGM_TOP_THREADS) b0[i] = in[(uint64_t)set * n0 + i];
+    }
+    __syncthreads();
+    for (uint32_t d = d0; d < d1; d++) {
+        const uint32_t np = 8u << d;  // parent Blocks of this set
+        const blk_t *src = (d & 1) ? bufB : bufA;
+        blk_t *dst = (d & 1) ? bufA : bufB;
+        const bool to_hbm = d + 1 == d1;
+        blk_t *gout = out + (uint64_t)set * np * 2;
+        blk_t acc0 = bzero(), acc1 = bzero();
+        for (uint32_t idx = threadIdx.x; idx < np; idx += GGM_TOP_THREADS) {
+            const blk_t p = src[idx];
+            const blk_t c0 = bxor(aes_encrypt(te, c_rk_fixed[AES_K0], p), p);
+            const blk_t c1 = bxor(aes_encrypt(te, c_rk_fixed[AES_K1], p), p);
+            acc0 = bxor(acc0, c0);
+            acc1 = bxor(acc1, c1);
+            const uint32_t node = idx >> 3, t8 = idx & 7;
+            blk_t *o = to_hbm ? gout : dst;
+            o[(2 * node) * 8 + t8] = c0;
+            o[(2 * node + 1) * 8 + t8] = c1;
+        }
+        for (int off = 8; off < 64; off <<= 1) {
+            acc0.x ^= __shfl_xor(acc0.x, off), acc0.y ^= __shfl_xor(acc0.y, off);
+            acc0.z ^= __shfl_xor(acc0.z, off), acc0.w ^= __shfl_xor(acc0.w, off);
+            acc1.x ^= __shfl_xor(acc1.x, off), acc1.y ^= __shfl_xor(acc1.y, off);
+            acc1.z ^= __shfl_xor(acc1.z, off), acc1.w ^= __shfl_xor(acc1.w, off);
+        }
+        if (lane < 8) {
+            red[wave][0][lane] = acc0;
+            red[wave][1][lane] = acc1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const uint32_t keep = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+            blk_t sacc = red[0][keep][t8];
+            for (int w = 1; w < GGM_TOP_THREADS / 64; w++) sacc = bxor(sacc, red[w][keep][t8]);
+            lsum[keep][t8] = sacc;
+            sums[(((uint64_t)d * nsets + set) * 2 + keep) * 8 + t8] = sacc;  // the only workgroup of this set: no atomics
+        }
+        __syncthreads();
+        if (RECV && !to_hbm && threadIdx.x < 8) {
+            // repair the inactive child of the active parent on level d + 1 (pprf.rs:456-467)
+            const uint32_t j = threadIdx.x, tr = set * 8 + j;
+            const uint64_t leaf = active_path(choices + (uint64_t)tr * depth, depth);
+            const uint64_t inactive = (leaf >> (depth - 1 - d)) ^ 1;
+            const uint32_t not_ai = inactive & 1;
+            blk_t v = dst[inactive * 8 + j];
+            v = bxor(v, tg_sums[(((uint64_t)set * 2 + not_ai) * (depth - 1) + d) * 8 + j]);
+            v = bxor(v, lsum[not_ai][j]);
+            v = bxor(v, base[(uint64_t)tr * depth + d]);
+            dst[inactive * 8 + j] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sender: mask level sums with the base OTs, build the last-level 4-tuples (pprf.rs:199-254)
 __global__ void k_sender_treegrp(const blk_t *__restrict__ sums, const blk_t *__restrict__ base /*[tr*depth+d][2]*/,
@@ -367,7 +448,25 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     // sender: levels 0..depth-1 from the roots in lvl_a; receiver: levels 1..depth-1 from level 1 in lvl_b
     blk_t *cur = receiver ? c->lvl_b : c->lvl_a;
     blk_t *nxt = receiver ? c->lvl_a : c->lvl_b;
-    for (uint32_t d = receiver ? 1 : 0; d < depth; d++) {
+    uint32_t dstart = receiver ? 1 : 0;
+    // levels dstart .. d1-1 in LDS (k_ggm_top); level d1 lands in nxt. The leaf level always goes through k_ggm_level<true>.
+    const uint32_t d1 = depth - 1 < GGM_TOP_MAXLVL ? depth - 1 : GGM_TOP_MAXLVL;
+    if (d1 > dstart && !getenv("SOT_NO_GGM_TOP")) {
+        if (receiver) {
+            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<true>, dim3(nsets), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
+                       c->sums, c->d_base, c->d_choices, c->d_tg_sums, depth);
+            SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), c->d_base, c->d_choices,
+                       c->d_tg_sums, c->sums + (uint64_t)(d1 - 1) * nsets * 16, (uint32_t)c->conf.parts, depth, d1 - 1, nxt);
+        } else {
+            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<false>, dim3(nsets), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
+                       c->sums, (const blk_t *)nullptr, (const uint8_t *)nullptr, (const blk_t *)nullptr, depth);
+        }
+        blk_t *t = cur;
+        cur = nxt;
+        nxt = t;
+        dstart = d1;
+    }
+    for (uint32_t d = dstart; d < depth; d++) {
         uint64_t per_set = (uint64_t)8 << d;
         unsigned gx = grid_for(per_set, GGM_BLOCK, 256);
         dim3 grid(gx, nsets);
