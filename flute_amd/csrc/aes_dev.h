@@ -42,7 +42,9 @@ __device__ __forceinline__ void aes_lds_fill(uint32_t (*te)[AES_LDS_WORDS]) {
 #define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define OR_XOR(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x56)  // (a | b) ^ c
 
-// rk: AES_RK_WORDS words (plain, then rotated right by 8)
+// rk: AES_RK_WORDS words (plain, then rotated right by 8); ROT_INLINE: only the 44 plain words exist (per-lane keys
+// kept in LDS, alsz.hip) and the rotation is one v_alignbit per column
+template <bool ROT_INLINE = false>
 __device__ __forceinline__ blk_t aes_encrypt(const uint32_t (*te)[AES_LDS_WORDS], const uint32_t *__restrict__ rk,
                                              blk_t in) {
     const char *tb = (const char *)te[0];
@@ -57,10 +59,12 @@ __device__ __forceinline__ blk_t aes_encrypt(const uint32_t (*te)[AES_LDS_WORDS]
     uint32_t s0 = in.x ^ rk[0], s1 = in.y ^ rk[1], s2 = in.z ^ rk[2], s3 = in.w ^ rk[3];
 #pragma unroll
     for (int r = 1; r < 10; r++) {
-        const uint32_t t0 = COL(s0, s1, s2, s3, rk[44 + 4 * r]);
-        const uint32_t t1 = COL(s1, s2, s3, s0, rk[44 + 4 * r + 1]);
-        const uint32_t t2 = COL(s2, s3, s0, s1, rk[44 + 4 * r + 2]);
-        const uint32_t t3 = COL(s3, s0, s1, s2, rk[44 + 4 * r + 3]);
+#define RKR(i) (ROT_INLINE ? rotl32(rk[(i)], 24) : rk[44 + (i)])
+        const uint32_t t0 = COL(s0, s1, s2, s3, RKR(4 * r));
+        const uint32_t t1 = COL(s1, s2, s3, s0, RKR(4 * r + 1));
+        const uint32_t t2 = COL(s2, s3, s0, s1, RKR(4 * r + 2));
+        const uint32_t t3 = COL(s3, s0, s1, s2, RKR(4 * r + 3));
+#undef RKR
         s0 = t0, s1 = t1, s2 = t2, s3 = t3;
     }
     // last round: SubBytes + ShiftRows only. TE0 bytes are (2S, S, S, 3S): bytes 1 and 2 hold S[x]; two byte

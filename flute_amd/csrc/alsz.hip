@@ -1,0 +1,152 @@
+// ALSZ13 OT extension on gfx950: the local work of zappot::ot_ext::{Sender, Receiver}
+// (crates/zappot/src/ot_ext/mod.rs:48-142, :156-237) after the 128 base OTs exist.
+//
+//   receiver (:193-235): t_row[r] = PRG(s0_r), u_row[r] = PRG(s1_r) ^ t_row[r] ^ choices  (r < 128, count/8 bytes each),
+//                        T = transpose(t_mat, 128, count), out[i] = H(T_i)
+//   sender   (:91-140) : v_row[r] = PRG(seed_r) ^ (base_choice_r ? u_row[r] : 0), Q = transpose(v_mat, 128, count),
+//                        out[i] = [H(Q_i), H(Q_i ^ delta)], delta = the 128 base choices as a Block
+//   PRG = AesRng (util/aes_rng.rs:101-136): block j of a row = AES_seed(LE128(j)); H = cr_hash_block (aes_hash.rs:26-30);
+//   transpose = util/transpose.rs:5-14 (bit r of output Block i = bit i of row r, Lsb0 bytes).
+//
+// One tile = keystream block j of all 128 rows = OTs 128 j .. 128 j + 127: thread r encrypts counter j under row r's
+// key (the 128 or 256 expanded keys sit in LDS, 44 words each), the 128 x 128 bit tile is transposed through LDS and
+// every thread hashes one OT. Workgroups of 1024 threads take 8 tiles at a time.
+#include <string.h>
+
+#include <vector>
+
+#include "aes_dev.h"
+#include "sot_internal.h"
+
+#define AZ_THREADS 1024
+#define AZ_TILES (AZ_THREADS / 128)
+
+template <bool SENDER>
+__global__ void __launch_bounds__(AZ_THREADS)
+    k_alsz(const uint32_t *__restrict__ rks /* SENDER: [128][44], else [128][2][44] */, const blk_t *__restrict__ choices,
+           blk_t delta, const uint8_t *__restrict__ base_choice /* SENDER: [128] 0/1 */, blk_t *__restrict__ U /* [128][nj] */,
+           uint64_t nj, uint64_t count, blk_t *__restrict__ out) {
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
+    __shared__ uint32_t keys[128 * (SENDER ? 1 : 2) * 44];
+    __shared__ uint32_t tile[AZ_TILES][128][5];  // padded rows
+    aes_lds_fill(te);
+    for (uint32_t i = threadIdx.x; i < 128 * (SENDER ? 1 : 2) * 44; i += AZ_THREADS) keys[i] = rks[i];
+    __syncthreads();
+    const uint32_t r = threadIdx.x & 127, tl = threadIdx.x >> 7;
+    const uint32_t *k0 = keys + r * (SENDER ? 44 : 88);
+    const uint32_t rbit = SENDER ? base_choice[r] : 0;
+    for (uint64_t j0 = (uint64_t)blockIdx.x * AZ_TILES; j0 < nj; j0 += (uint64_t)gridDim.x * AZ_TILES) {
+        const uint64_t j = j0 + tl;
+        if (j < nj) {
+            const blk_t ctr = make_uint4((uint32_t)j, (uint32_t)(j >> 32), 0, 0);
+            blk_t t = aes_encrypt<true>(te, k0, ctr);
+            if (SENDER) {
+                if (rbit) t = bxor(t, U[(uint64_t)r * nj + j]);  // v ^= r_j * u_j (:118-126)
+            } else {
+                const blk_t u = bxor(bxor(aes_encrypt<true>(te, k0 + 44, ctr), t), choices[j]);  // :212-217
+                U[(uint64_t)r * nj + j] = u;
+            }
+            tile[tl][r][0] = t.x, tile[tl][r][1] = t.y, tile[tl][r][2] = t.z, tile[tl][r][3] = t.w;
+        }
+        __syncthreads();
+        if (j < nj) {
+            // OT i = 128 j + r: bit q of its Block = bit r of row q
+            const uint32_t rw = r >> 5, rb = r & 31;
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t w = 0;
+#pragma unroll 8
+                for (int b = 0; b < 32; b++) w |= ((tile[tl][32 * q + b][rw] >> rb) & 1u) << b;
+                o[q] = w;
+            }
+            const uint64_t i = 128 * j + r;
+            if (i < count) {
+                const blk_t x = make_uint4(o[0], o[1], o[2], o[3]);
+                if (SENDER) {
+                    out[2 * i] = cr_hash(te, x);
+                    out[2 * i + 1] = cr_hash(te, bxor(x, delta));
+                } else {
+                    out[i] = cr_hash(te, x);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int alsz_run(bool sender, int device, const void *base_ots, const uint8_t *choice_bytes, const void *base_choices,
+                    uint8_t *u_rows, uint64_t count, void *msgs_out) {
+    if (!base_ots || !u_rows || !msgs_out || (sender ? !base_choices : !choice_bytes)) return SOT_EINVAL;
+    if (count == 0 || count % 8) {
+        sot_set_error("alsz: the number of OT extensions must be a positive multiple of 8 (ot_ext/mod.rs:58-62)");
+        return SOT_EINVAL;
+    }
+    SOT_HIP(hipSetDevice(device));
+    const uint64_t cols = count / 8, nj = (count + 127) / 128, nkeys = sender ? 128 : 256;
+    std::vector<uint32_t> rks(nkeys * 44);
+    for (uint64_t k = 0; k < nkeys; k++) {
+        aes_rk rk;
+        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
+        memcpy(&rks[k * 44], rk.w, 176);
+    }
+    std::vector<uint8_t> bc(128, 0);
+    blk_t delta = make_uint4(0, 0, 0, 0);
+    if (sender) {
+        memcpy(&delta, base_choices, 16);
+        for (int i = 0; i < 128; i++) bc[i] = (((const uint8_t *)base_choices)[i >> 3] >> (i & 7)) & 1;
+    }
+    // padded images: choices as nj Blocks, U as [128][nj] Blocks
+    std::vector<uint8_t> pad(nj * 16, 0), ubuf((size_t)128 * nj * 16, 0);
+    if (!sender) memcpy(pad.data(), choice_bytes, cols);
+    if (sender)
+        for (int r = 0; r < 128; r++) memcpy(&ubuf[(size_t)r * nj * 16], u_rows + (size_t)r * cols, cols);
+    uint32_t *d_rks = nullptr;
+    blk_t *d_ch = nullptr, *d_U = nullptr, *d_out = nullptr;
+    uint8_t *d_bc = nullptr;
+    const uint64_t out_bytes = count * (sender ? 32 : 16);
+    int rc = SOT_OK;
+    if (hipMalloc((void **)&d_rks, rks.size() * 4) != hipSuccess || hipMalloc((void **)&d_ch, nj * 16) != hipSuccess ||
+        hipMalloc((void **)&d_U, (size_t)128 * nj * 16) != hipSuccess || hipMalloc((void **)&d_out, out_bytes) != hipSuccess ||
+        hipMalloc((void **)&d_bc, 128) != hipSuccess)
+        rc = SOT_ENOMEM;
+    if (rc == SOT_OK) {
+        (void)hipMemcpy(d_rks, rks.data(), rks.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_ch, pad.data(), nj * 16, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_bc, bc.data(), 128, hipMemcpyHostToDevice);
+        if (sender) (void)hipMemcpy(d_U, ubuf.data(), ubuf.size(), hipMemcpyHostToDevice);
+        uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
+        if (g > 512) g = 512;
+        if (sender)
+            hipLaunchKernelGGL(k_alsz<true>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, delta, d_bc, d_U, nj,
+                               count, d_out);
+        else
+            hipLaunchKernelGGL(k_alsz<false>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, delta, d_bc, d_U, nj,
+                               count, d_out);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(msgs_out, d_out, out_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && !sender) {
+            e = hipMemcpy(ubuf.data(), d_U, ubuf.size(), hipMemcpyDeviceToHost);
+            for (int r = 0; r < 128 && e == hipSuccess; r++) memcpy(u_rows + (size_t)r * cols, &ubuf[(size_t)r * nj * 16], cols);
+        }
+        if (e != hipSuccess) {
+            sot_set_error("alsz: %s", hipGetErrorString(e));
+            rc = SOT_EDEVICE;
+        }
+    } else {
+        sot_set_error("alsz: device allocation failed");
+    }
+    void *ptrs[] = {d_rks, d_ch, d_U, d_out, d_bc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+extern "C" int sot_alsz_receive(int device, const void *base_ots, const uint8_t *choice_bytes, uint64_t count,
+                                uint8_t *u_rows_out, void *msgs_out) {
+    return alsz_run(false, device, base_ots, choice_bytes, nullptr, u_rows_out, count, msgs_out);
+}
+extern "C" int sot_alsz_send(int device, const void *base_ots, const void *base_choices, const uint8_t *u_rows,
+                             uint64_t count, void *msgs_out) {
+    return alsz_run(true, device, base_ots, nullptr, base_choices, (uint8_t *)u_rows, count, msgs_out);
+}

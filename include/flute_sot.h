@@ -151,6 +151,18 @@ int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
 /* triples left in the context's store (MulTriples::len after the split_off_last calls so far) */
 uint64_t sot_mt_remaining(const sot_ctx *ctx);
 
+/* ---- ALSZ13 OT extension: zappot::ot_ext after the 128 base OTs ---------------------------------- */
+/* Receiver::receive_random, local part (zappot/src/ot_ext/mod.rs:193-235). base_ots: [128][2] Blocks (the base-OT
+ * sender's message pairs); choice_bytes: count/8 bytes, Lsb0 (BitSlice<usize> raw bytes); count % 8 == 0.
+ * u_rows_out: [128][count/8] bytes, row idx = the ExtOTMsg::URow(idx, row) payloads; msgs_out: count Blocks. */
+int sot_alsz_receive(int device, const void *base_ots, const uint8_t *choice_bytes, uint64_t count, uint8_t *u_rows_out,
+                     void *msgs_out);
+/* Sender::send_random, local part (:91-140). base_ots: [128] Blocks (the base-OT receiver's outputs); base_choices: the
+ * 128 base choices as 16 Lsb0 bytes (= delta, :88-90); u_rows: the peer's [128][count/8] bytes. msgs_out: count x
+ * [Block; 2]. */
+int sot_alsz_send(int device, const void *base_ots, const void *base_choices, const uint8_t *u_rows, uint64_t count,
+                  void *msgs_out);
+
 /* ---- whole-direction pipelines (random_silent_send / random_silent_receive) --------------- */
 /* silent_ot/mod.rs:193-211. msgs_out may be NULL (results stay in HBM). */
 int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed,
