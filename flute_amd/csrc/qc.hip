@@ -31,6 +31,9 @@
 // without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
 #define QC_EXP 0
 #endif
+#ifndef QC_MIDMASK_LDS
+#define QC_MIDMASK_LDS 1  // k_mid: level masks through the wave's own LDS slots (1) or through the scalar unit (0)
+#endif
 #ifndef QC_LOWMASK_LDS
 #define QC_LOWMASK_LDS 1  // k_fft_low<1>: intra-word masks through LDS (1) or through the scalar unit (0)
 #endif
@@ -1455,7 +1458,7 @@ __global__ void __launch_bounds__(MD_THREADS)
         mask_prefetch(pf, MT + ((((uint64_t)o2 * 4 + (lane >> 4)) * 8 + bf) << 8) + (lane & 15) * 16);
     };
     uint32_t pf = 0;
-    masks_ahead(pf, idx);
+    if (!QC_MIDMASK_LDS) masks_ahead(pf, idx);
     regs_t v = fetch(idx);
 #pragma unroll 1
     for (uint32_t sq = 0; sq < nseq; sq++) {
@@ -1469,7 +1472,16 @@ __global__ void __launch_bounds__(MD_THREADS)
         {
             const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
             v = fetch(nidx);
-            if (!(nidx & 1)) masks_ahead(pf, nidx);
+            if (!QC_MIDMASK_LDS && !(nidx & 1)) masks_ahead(pf, nidx);
+        }
+        // QC_MIDMASK_LDS: the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and
+        // parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
+        // registers) and read back as VGPR operands: no scalar-memory stream whose latency the level would expose
+        uint4 mk[4];
+        if (QC_MIDMASK_LDS) {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                mk[b] = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
         }
 #pragma unroll
         for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
@@ -1489,7 +1501,23 @@ __global__ void __launch_bounds__(MD_THREADS)
 #pragma unroll
                 for (int k = 0; k < 16; k++) y[k] ^= x[k];
             }
-            apply_masks16(x, y, M);
+            if (QC_MIDMASK_LDS) {
+                uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
+                R[lane] = mk[b];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+#pragma unroll
+                    for (int kq = 0; kq < 4; kq++) {
+                        const uint4 m = R[j * 4 + kq];
+                        x[4 * kq + 0] = XAND(x[4 * kq + 0], y[j], m.x);
+                        x[4 * kq + 1] = XAND(x[4 * kq + 1], y[j], m.y);
+                        x[4 * kq + 2] = XAND(x[4 * kq + 2], y[j], m.z);
+                        x[4 * kq + 3] = XAND(x[4 * kq + 3], y[j], m.w);
+                    }
+                }
+            } else {
+                apply_masks16(x, y, M);
+            }
 #pragma unroll
             for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
             if (!pruned) {
