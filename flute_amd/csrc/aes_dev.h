@@ -32,9 +32,12 @@ typedef uint32_t aes_lds_t[1][AES_LDS_WORDS];
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 
 __device__ __forceinline__ void aes_lds_fill(uint32_t (*te)[AES_LDS_WORDS]) {
-    for (uint32_t i = threadIdx.x; i < AES_LDS_WORDS; i += blockDim.x) {
-        const uint32_t t = d_TE0[i >> 6];
-        te[0][i] = (i & 32) ? rotl32(t, 16) : t;
+    // four replicas per 16-byte store (words 4 i .. 4 i + 3 lie in the same half row)
+    uint4 *t4 = (uint4 *)te[0];
+    for (uint32_t i = threadIdx.x; i < AES_LDS_WORDS / 4; i += blockDim.x) {
+        const uint32_t t = d_TE0[i >> 4];
+        const uint32_t v = (i & 8) ? rotl32(t, 16) : t;
+        t4[i] = make_uint4(v, v, v, v);
     }
     __syncthreads();
 }

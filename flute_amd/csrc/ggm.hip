@@ -468,7 +468,9 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     }
     for (uint32_t d = dstart; d < depth; d++) {
         uint64_t per_set = (uint64_t)8 << d;
-        unsigned gx = grid_for(per_set, GGM_BLOCK, 256);
+        // interior levels: few, longer-lived workgroups (each fills the 64 KiB AES table once; 15 sets x 64 ~ 4 per CU);
+        // the leaf level has enough work per workgroup and balances better with many
+        unsigned gx = grid_for(per_set, GGM_BLOCK, d + 1 < depth ? 64 : 256);
         dim3 grid(gx, nsets);
         blk_t *lsum = c->sums + (uint64_t)d * nsets * 16;
         if (d + 1 < depth) {
