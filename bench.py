@@ -258,6 +258,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": dom_name, "kernel_avg_ms": dom_ms / max(dom_cnt, 1), "kernel_launches_per_step": dom_cnt,
+                # the same 48 B/OT x n of one direction against the dominant kernel's launch alone
+                "dominant_kernel_achieved": (QC_BYTES_PER_OT * n) / (dom_ms / max(dom_cnt, 1) * 1e-3) / 1e9,
+                "dominant_kernel_frac": (QC_BYTES_PER_OT * n) / (dom_ms / max(dom_cnt, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "basis": "QC-encode stage: 48 B/OT x n per direction / summed device time of the stage's kernels "
                          "per direction (%.3f ms); dominant kernel named" % (qc_ms / 2.0),
             }
