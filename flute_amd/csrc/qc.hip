@@ -148,36 +148,6 @@ __global__ void k_a_load(const uint32_t *__restrict__ abits, uint64_t nbits, uin
     Z[w * ROWS] = v;
 }
 
-// K9: row words -> Blocks: T[32 w + p] bit row = Z[w][row] bit p.
-#define ST_W 64
-__global__ void __launch_bounds__(256) k_qc_store(const uint32_t *__restrict__ Z, uint64_t nw, blk_t *__restrict__ T) {
-    __shared__ uint32_t tin[ST_W * 129];   // [w][row]
-    __shared__ uint32_t tout[ST_W * 132];  // [w][p][q]
-    const uint64_t w0 = (uint64_t)blockIdx.x * ST_W;
-    for (uint32_t i = threadIdx.x; i < ST_W * ROWS; i += 256) {
-        const uint64_t w = w0 + (i >> 7);
-        tin[(i >> 7) * 129 + (i & 127)] = w < nw ? Z[w * ROWS + (i & 127)] : 0u;
-    }
-    __syncthreads();
-    {
-        const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
-        uint32_t a[32];
-#pragma unroll
-        for (int b = 0; b < 32; b++) a[b] = tin[wl * 129 + 32 * q + b];
-        transpose32(a);
-#pragma unroll
-        for (int p = 0; p < 32; p++) tout[wl * 132 + p * 4 + q] = a[p];
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ST_W * 32; i += 256) {
-        const uint64_t c = w0 * 32 + i;
-        if (c < nw * 32) {
-            const uint32_t *s = tout + (i >> 5) * 132 + (i & 31) * 4;
-            T[c] = make_uint4(s[0], s[1], s[2], s[3]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2: one phase of the monomial <-> novel basis conversion (gf2fft_model.conversion_phases):
 //   out[i] = in[i] ^ m1(l) in[i + D] ^ m2(l) in[i + 2D],  l = i mod chunk, D = half - pw
@@ -1799,46 +1769,6 @@ __device__ __forceinline__ blk_t ld_v1p(const blk_t *V1, uint64_t v1_len, uint64
     return v;
 }
 
-__global__ void __launch_bounds__(256)
-    k_qc_final(const blk_t *__restrict__ V, uint64_t nb128, uint64_t P, uint64_t S, uint64_t tail, uint64_t n,
-               const blk_t *__restrict__ T, uint64_t t_len, const uint32_t *__restrict__ a2,
-               const uint32_t *__restrict__ a_hi /* tail bits, packed */, blk_t *__restrict__ out) {
-    const blk_t *V1 = V + nb128;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
-        blk_t r = V[k];
-        if (k + P < nb128) {
-            blk_t u = V[k + P];
-            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-        }
-        for (uint64_t m = k; m < t_len; m += P) {
-            blk_t u = T[m];
-            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-        }
-        if (tail) {
-            // q = (k - S) mod P
-            uint64_t q = k >= S ? k - S : k + P - S;
-            for (uint64_t i = 0; i < tail; i++) {
-                if ((a_hi[i >> 5] >> (i & 31)) & 1u) {
-                    uint64_t c = q >= i ? q - i : q + P - i;
-                    blk_t u = ld_v1p(V1, nb128, P, c);
-                    r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-                }
-            }
-            for (uint64_t j = 0; j < tail; j++) {
-                uint64_t c = q >= j ? q - j : q + P - j;  // index into a'
-                if (c < S) {
-                    uint32_t bit = (a2[c >> 5] >> (c & 31)) & 1u;
-                    if (bit) {
-                        blk_t u = ld_v1p(V1, nb128, P, S + j);
-                        r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-                    }
-                }
-            }
-        }
-        out[k] = r;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K10 fused with K9: product rows -> Blocks, fold mod x^P - 1, add V0 and the tail terms, in one pass (no T):
 //   B[k] = V0[k] ^ V0[k+P] ^ C[k] ^ C[k+P] ^ sum_{i: a_hi[i]} V1'[(q - i) mod P] ^ sum_{j < tail} a_lo[(q - j) mod P] V1'[S + j]
@@ -2385,7 +2315,7 @@ int qc_init(sot_ctx *c) {
         return SOT_EINVAL;
     }
     // FFT capacity: 2^m product bits, S = 2^(m-1) bits per operand; up to TAIL_MAX operand bits above S go
-    // through the tail terms of k_qc_final. m >= 21 keeps all five pruned levels on word-index bits.
+    // through the tail terms of k_qc_finish. m >= 21 keeps all five pruned levels on word-index bits.
     const uint64_t TAIL_MAX = 256;
     uint32_t m = 21;
     while ((1ull << (m - 1)) + TAIL_MAX < cf.P) m++;
@@ -2402,7 +2332,6 @@ int qc_init(sot_ctx *c) {
     SOT_TRY(dev_alloc(c, (void **)&c->Z1, g.nw * ROWS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * 1024 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * 512 * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->T, 2 * g.S * 16));
     SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 256 * 32 * 4));
@@ -2437,7 +2366,7 @@ int qc_init(sot_ctx *c) {
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->T, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }

@@ -111,7 +111,6 @@ struct sot_ctx {
     void *qc_plan = nullptr;                // fft_plan (qc.hip): tile descriptors of the passes
     uint32_t *up_list = nullptr;            // move lists of the whole-unit conversion phases
     uint32_t *Amat = nullptr;               // per value word multiply-by-FFT(a) bit matrices [nw/32][32][32]
-    blk_t *T = nullptr;                     // product a_lo * b_lo in Block form, 2 S Blocks
     uint32_t *a2 = nullptr;                 // a mod (x^P - 1), bit vector repeated twice (words)
     uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
     std::vector<uint32_t> a_hi_host;
