@@ -175,9 +175,10 @@ def test_odd_sizes_match_oracle(orc, n, T):
     _encode_both_vs_oracle(orc, n, T, n % 9973)
 
 
-def test_2pow26_sender_matches_oracle(orc):
-    """BASELINE.json's largest size: 2^26 OTs (FFT of 2^23 points, twiddles outside GF(2^16), generic
-    conversion path). Needs oracle/_ref for a tolerable oracle run time."""
+@pytest.mark.parametrize("log2n", [25, 26])
+def test_large_sender_matches_oracle(orc, log2n):
+    """2^25 and BASELINE.json's largest size 2^26 (m = 26, 27: extra 32-plane passes, whole-unit conversion phases in
+    k_conv_wholeunits instead of the top pass). Needs oracle/_ref for a tolerable oracle run time."""
     if orc.ref_lib() is None:
         pytest.skip("oracle/_ref absent")
-    _encode_both_vs_oracle(orc, 1 << 26, 4, 26, receiver=False)
+    _encode_both_vs_oracle(orc, 1 << log2n, 4, log2n, receiver=False)
