@@ -78,18 +78,17 @@ __device__ __forceinline__ uint32_t range_mask(int64_t lo, int64_t hi) {
 // ------------------------------------------------------------------------------------------------
 // receiver with packed choice bits: bit 0 of the leaf vector is replaced by the noise indicator sb
 // (silent_ot/mod.rs:560-574, quasi_cyclic_encode.rs:92-100)
-__global__ void k_clear_lsb(blk_t *__restrict__ V, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t *p = (uint32_t *)(V + i);
-        *p &= ~1u;
-    }
-}
-__global__ void k_set_points(blk_t *__restrict__ V, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t nV) {
+// The leaves V are never modified: the noise indicator lives in a bit vector sb (one bit per Block of V, set at the
+// `parts` interleaved points) and every load of V on the receiver's encode path substitutes it for bit 0.
+__global__ void k_set_points(uint32_t *__restrict__ sb, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t nV) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < npts && pts[i] < nV) {
-        uint32_t *p = (uint32_t *)(V + pts[i]);
-        atomicOr(p, 1u);
-    }
+    if (i < npts && pts[i] < nV) atomicOr(sb + (pts[i] >> 5), 1u << (pts[i] & 31));
+}
+// V[idx], with bit 0 := sb[idx] when sb != nullptr (receiver with packed choice bits)
+__device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t idx, const uint32_t *__restrict__ sb) {
+    blk_t v = V[idx];
+    if (sb) v.x = (v.x & ~1u) | ((sb[idx >> 5] >> (idx & 31)) & 1u);
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -101,17 +100,17 @@ __global__ void k_set_points(blk_t *__restrict__ V, const uint64_t *__restrict__
 #define LD_W 32
 #define LD_T 128
 __global__ void __launch_bounds__(LD_T)
-    k_qc_load(const blk_t *__restrict__ V1, uint64_t v1_len, uint64_t P, uint64_t lo_bits, uint64_t nw_half,
-              uint32_t *__restrict__ Z) {
+    k_qc_load(const blk_t *__restrict__ V, const uint32_t *__restrict__ sb, uint64_t v1_len, uint64_t P, uint64_t lo_bits,
+              uint64_t nw_half, uint32_t *__restrict__ Z) {
     __shared__ uint32_t tio[LD_W * 132];  // in: [w][p][q] words (stride 132); out: [w][row] (stride 129)
     const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
     for (uint32_t i = threadIdx.x; i < LD_W * 32; i += LD_T) {
         const uint64_t c = w0 * 32 + i;
         blk_t v = make_uint4(0, 0, 0, 0);
         if (c < lo_bits) {
-            v = V1[c];
+            v = ld_leaf(V, v1_len + c, sb);  // V1 = V + nb128 and v1_len == nb128
             if (c + P < v1_len) {
-                blk_t u = V1[c + P];
+                blk_t u = ld_leaf(V, v1_len + c + P, sb);
                 v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
             }
         }
@@ -1757,10 +1756,10 @@ __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64
 //   B[k] = V0[k] ^ V0[k+P] ^ T[k] ^ T[k+P] ^ sum_{i: a_hi[i]} V1'[(k - S - i) mod P]
 //                                         ^ sum_{j < tail} a_lo[(k - S - j) mod P] V1'[S + j]
 // V0 = V[0 .. nb128), V1' = (V1 mod x^P - 1). a2 = a' repeated twice as a bit vector.
-__device__ __forceinline__ blk_t ld_v1p(const blk_t *V1, uint64_t v1_len, uint64_t P, uint64_t c) {
-    blk_t v = V1[c];
+__device__ __forceinline__ blk_t ld_v1p(const blk_t *V, const uint32_t *sb, uint64_t v1_len, uint64_t P, uint64_t c) {
+    blk_t v = ld_leaf(V, v1_len + c, sb);  // V1 = V + nb128, v1_len == nb128
     if (c + P < v1_len) {
-        blk_t u = V1[c + P];
+        blk_t u = ld_leaf(V, v1_len + c + P, sb);
         v.x ^= u.x;
         v.y ^= u.y;
         v.z ^= u.z;
@@ -1783,16 +1782,15 @@ static inline size_t fn_dyn_lds(uint32_t tail) {
     return tail ? (size_t)(FN_K + 2 * tail) * 16 + ((FN_K + tail + 15) & ~15u) : 0;
 }
 __global__ void __launch_bounds__(256)
-    k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, uint64_t nb128, uint64_t P,
-                uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2, const uint32_t *__restrict__ a_hi,
-                blk_t *__restrict__ out) {
+    k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, const uint32_t *__restrict__ sb,
+                uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
+                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out) {
     __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
     // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
     extern __shared__ blk_t fn_dyn[];
     blk_t *win = fn_dyn;                                    // [FN_K + tail]  V1'[(c0 + x) mod P]
     blk_t *hi = fn_dyn + FN_K + tail;                       // [tail]         V1'[S + j]
     uint8_t *abit = (uint8_t *)(fn_dyn + FN_K + 2 * tail);  // [FN_K + tail]  0xff * a_lo[(c0 + x) mod P]
-    const blk_t *V1 = V + nb128;
     const uint64_t k0 = (uint64_t)blockIdx.x * FN_K;
     const uint64_t w0 = k0 >> 5;
     const uint64_t wsh = P >> 5;
@@ -1816,10 +1814,10 @@ __global__ void __launch_bounds__(256)
         for (uint32_t x = threadIdx.x; x < FN_K + tail - 1; x += 256) {
             uint64_t cc = c0 + x;
             if (cc >= P) cc -= P;
-            win[x] = ld_v1p(V1, nb128, P, cc);
+            win[x] = ld_v1p(V, sb, nb128, P, cc);
             abit[x] = cc < S ? (uint8_t)(0u - ((a2[cc >> 5] >> (cc & 31)) & 1u)) : (uint8_t)0;
         }
-        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V1, nb128, P, S + j);
+        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V, sb, nb128, P, S + j);
     }
     __syncthreads();
     {
@@ -1844,10 +1842,10 @@ __global__ void __launch_bounds__(256)
         if (k >= n) break;
         const uint32_t *sp = tio + (kl >> 5) * 132 + (kl & 31) * 4;
         blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        blk_t u = V[k];
+        blk_t u = ld_leaf(V, k, sb);
         r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         if (k + P < nb128) {
-            u = V[k + P];
+            u = ld_leaf(V, k + P, sb);
             r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         }
         if (tail && !(QC_EXP & 4)) {
@@ -2333,6 +2331,7 @@ int qc_init(sot_ctx *c) {
     SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * 1024 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * 512 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->sbv, (cf.cols * 128 / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 256 * 32 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 256 * 4));
@@ -2366,7 +2365,7 @@ int qc_init(sot_ctx *c) {
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->sbv, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
     for (void *p : ptrs)
         if (p) hipFree(p);
 }
@@ -2379,13 +2378,15 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     const uint64_t nb128 = cf.n_blocks * 128;
     const uint64_t nV = cf.cols * 128;
     const fft_plan &plan = *(const fft_plan *)c->qc_plan;
+    const uint32_t *sb = nullptr;
     if (role == SOT_ROLE_RECEIVER) {
         SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
-        SOT_LAUNCH(c, KID_CLEAR_LSB, k_clear_lsb, dim3(gridn(nV, 256, 4096)), dim3(256), V, nV);
-        SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), V, c->d_points,
-                           (uint32_t)npoints, nV);
+        SOT_HIP(hipMemsetAsync(c->sbv, 0, (nV / 32 + 2) * 4, c->stream));
+        SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), c->sbv, c->d_points,
+                   (uint32_t)npoints, nV);
+        sb = c->sbv;
     }
-    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V + nb128, nb128, cf.P, g.lo_bits,
+    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, nb128, cf.P, g.lo_bits,
                g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
@@ -2401,7 +2402,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     }
     if (c->prof) prof_begin(c, KID_QC_FINAL);
     hipLaunchKernelGGL(k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                       g.nw, V, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
+                       g.nw, V, sb, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
     if (c->prof) prof_end(c, KID_QC_FINAL);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));

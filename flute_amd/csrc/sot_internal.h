@@ -115,6 +115,7 @@ struct sot_ctx {
     uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
     std::vector<uint32_t> a_hi_host;
     uint64_t *d_points = nullptr;
+    uint32_t *sbv = nullptr;  // receiver noise indicator: one bit per Block of V (silent_ot/mod.rs:560-574)
     // MT bits
     uint64_t *d_mt = nullptr;  // a | b | c words
     bool mt_valid = false;     // set by hash_mt_bits, cleared by the next expand

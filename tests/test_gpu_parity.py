@@ -209,3 +209,21 @@ def test_mt_store_gather_single_rank(fa, orc):
         assert len(mts) == n and np.array_equal(mts.c, c)
     finally:
         e.close()
+
+
+def test_encode_leaves_receiver_rT_untouched(fa, orc):
+    """The receiver's noise vector sb (silent_ot/mod.rs:560-574) replaces bit row 0 only on the encode path's loads:
+    the expanded matrix itself (pprf::Receiver::expand's return value) is still intact after dual_encode2."""
+    n, T = 1000, 2
+    e = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(9)
+        y = fa.fake_base(e.conf, rng)
+        d, s = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(2))
+        tg = e.sender_expand(y[0], d, s, T)
+        e.receiver_expand(y[1], y[2], *tg)
+        before = e.download_rT(1)
+        e.qc_encode(1, e.points(y[2]))
+        assert np.array_equal(before, e.download_rT(1))
+    finally:
+        e.close()
