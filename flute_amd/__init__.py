@@ -10,3 +10,4 @@ from .silent_ot import (QuasiCyclicConf, Engine, Sender, Receiver, MultType,  # 
                         sample_base_choice_bits, fake_base)
 from .mul_triple import MulTriples, SilentMtProvider  # noqa: F401
 from .lut_setup import SetupCircuit, build_setup_circuit, replicate_setup_circuit, AndCircuit  # noqa: F401
+from . import wire  # noqa: F401

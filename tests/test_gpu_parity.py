@@ -148,6 +148,31 @@ def test_mirror_classes_random_ot(fa, orc):
         eng.close()
 
 
+def test_tree_groups_through_wire_codec(fa, orc):
+    """Sender's TreeGrps -> pprf::Msg::TreeGrp bytes (flute_amd/wire.py) -> shuffled arrival (pprf.rs:128: sender
+    threads emit them in any order) -> receiver: the OT relation still holds."""
+    from flute_amd import wire
+    n, T = 40000, 4
+    eng = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(9)
+        msg2, msg, choices = fa.fake_base(eng.conf, rng)
+        delta, seed = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(2))
+        snd = fa.Sender.new_with_silent_base_ots(eng, msg2, T)
+        rcv = fa.Receiver.new_with_silent_base_ots(eng, msg, choices, T)
+        s_out = snd.random_silent_send(delta, seed)
+        msgs = wire.tree_grps_to_msgs(eng.conf, *snd.tree_groups)
+        assert len(msgs) == eng.conf.parts // 8
+        msgs = [msgs[i] for i in rng.permutation(len(msgs))]
+        tg = wire.msgs_to_tree_grps(eng.conf, msgs)
+        assert all(np.array_equal(a, b) for a, b in zip(tg, snd.tree_groups))
+        r_out, ch = rcv.random_silent_receive(tg)
+        sel = np.unpackbits(ch.view(np.uint8), bitorder="little")[:n].astype(np.int64)
+        assert np.array_equal(s_out[np.arange(n), sel], r_out)
+    finally:
+        eng.close()
+
+
 def test_two_party_mt_relation(fa, orc):
     """c1 ^ c2 == (a1 ^ a2) & (b1 ^ b2) (gmw/src/mul_triple/silent_ot.rs:166-168) with two providers."""
     n, T = 3000, 3
