@@ -2178,7 +2178,12 @@ static fft_plan make_plan(uint32_t m) {
         if (cnt > 4) cnt = 4;
         std::vector<uint32_t> lv;
         for (uint32_t k = 0; k < cnt; k++) lv.push_back(r + k);
-        p.w32.push_back(make_desc(m, {1, 2, 4, 8, 16}, lv));
+        // 5 plane bits + cnt level bits are only 2^(5+cnt) slots: fill the tile up to 2^8 slots with the lowest word
+        // bits (independent batches below every level bit, so the twiddles do not depend on them): 16 work items
+        // per level = one per wave, and neighbouring 512-B granules per tile
+        std::vector<uint32_t> batch;
+        for (uint32_t b = 0; 5 + cnt + batch.size() < 8 && !getenv("SOT_W32_SMALL"); b++) batch.push_back(b);
+        p.w32.push_back(make_desc(m, {1, 2, 4, 8, 16}, lv, batch));
         r += cnt;
     }
     std::vector<uint32_t> lv;
