@@ -56,7 +56,7 @@ def main():
 
 
     # profiles/pmc_latest.json: what bench.py reports as roofline.traffic (dominant kernel, per launch)
-    dom = "k_fft_low<1>"
+    dom = next((k for k in pmc if k.startswith("k_fft_low<1")), "k_fft_low<1>")
     if dom in pmc and "FETCH_SIZE" in pmc[dom] and "WRITE_SIZE" in pmc[dom]:
         import json
         e = pmc[dom]
