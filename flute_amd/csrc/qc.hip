@@ -609,6 +609,8 @@ struct taylor_desc {
     uint32_t lnc;  // log2(columns per tile, halo included)
     uint32_t hw;   // halo columns
     uint32_t lrq;  // log2(row quads per tile)
+    uint32_t lg;   // log2(column stride in words): every shift of the tile's phases is a multiple of 2^lg words, so
+                   // the words with equal index mod 2^lg form independent problems; a tile takes one residue g
     uint32_t nph;
     uint8_t lchunk[8], lpw[8];
 };
@@ -627,7 +629,7 @@ __device__ __forceinline__ u4 ty_fetch(const u4 *lds, const taylor_desc &t, bool
 __device__ __forceinline__ void ty_shift(u4 *lds, const taylor_desc &t, bool wrap, uint32_t lchunk, uint32_t lpw) {
     const uint32_t lhalf = lchunk - 1 - t.lus;  // log2(units per half chunk)
     const uint32_t half_u = 1u << lhalf;
-    const uint32_t sw = (1u << lpw) >> 5, sb = (1u << lpw) & 31u;
+    const uint32_t sw = ((1u << lpw) >> 5) >> t.lg, sb = (1u << lpw) & 31u;
     const uint32_t items = 1u << (t.lnu - 1 + t.lnc + t.lrq);
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
         const uint32_t r = it & ((1u << t.lrq) - 1u);
@@ -646,7 +648,7 @@ __device__ __forceinline__ void ty_fold(u4 *lds, const taylor_desc &t, bool wrap
     const uint32_t lhalf = lchunk - 1 - t.lus;
     const uint32_t half_u = 1u << lhalf;
     const uint32_t nchunks = 1u << (t.lnu - lhalf - 1);
-    const uint32_t sw = (1u << lpw) >> 5, sb = (1u << lpw) & 31u;
+    const uint32_t sw = ((1u << lpw) >> 5) >> t.lg, sb = (1u << lpw) & 31u;
     const uint32_t nx = sb ? 1u : sw;
     const uint32_t items = (nchunks * nx) << t.lrq;
     for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
@@ -662,19 +664,20 @@ __device__ __forceinline__ void ty_fold(u4 *lds, const taylor_desc &t, bool wrap
 // element `it` (of the 8192 of a tile) of tile `b`, zero outside the unit
 __device__ __forceinline__ u4 ty_ld(const uint32_t *__restrict__ Din, const taylor_desc &t, uint32_t ncoltiles, uint32_t b,
                                     uint32_t it) {
-    const uint32_t UW = 1u << (t.lus - 5);  // words per unit
+    const uint32_t UW = 1u << (t.lus - 5 - t.lg);  // columns per unit
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
     const uint32_t nrg = 32u >> t.lrq;  // row groups
-    const uint32_t rg = b % nrg, cb = (b / nrg) % ncoltiles, grp = (b / nrg) / ncoltiles;
+    const uint32_t rg = b % nrg, g = (b / nrg) & ((1u << t.lg) - 1u), bc = (b / nrg) >> t.lg;
+    const uint32_t cb = bc % ncoltiles, grp = bc / ncoltiles;
     const uint32_t o0 = cb * W;
     const bool wrap = o0 == 0;
-    const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
+    const uint64_t gbase = (((uint64_t)grp << (t.lnu + t.lus - 5)) + g) * ROWS + (rg << (t.lrq + 2));
     const uint32_t r = it & ((1u << t.lrq) - 1u);
     const uint32_t col = (it >> t.lrq) & (NC - 1);
     const uint32_t u = it >> (t.lrq + t.lnc);
     const uint32_t o = col >= t.hw ? o0 + col - t.hw : (wrap ? UW - t.hw + col : o0 - t.hw + col);
     u4 v = {0, 0, 0, 0};
-    if (o < UW) v = ld_u4(Din + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r);
+    if (o < UW) v = ld_u4(Din + gbase + ((((uint64_t)u * UW + o)) << t.lg) * ROWS + 4 * r);
     return v;
 }
 __device__ __forceinline__ cu_regs ty_fetch_tile(const uint32_t *__restrict__ Din, const taylor_desc &t, uint32_t ncoltiles,
@@ -694,7 +697,7 @@ __global__ void __launch_bounds__(CT_THREADS)
     k_conv_taylor(const uint32_t *__restrict__ Din, uint32_t *__restrict__ Dout, taylor_desc t, uint32_t ncoltiles,
                   int inverse, uint32_t ntiles) {
     __shared__ u4 lds[8192];
-    const uint32_t UW = 1u << (t.lus - 5);  // words per unit
+    const uint32_t UW = 1u << (t.lus - 5 - t.lg);  // columns per unit
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
     const uint32_t nrg = 32u >> t.lrq;  // row groups
     const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);  // == 8192 (make_taylor)
@@ -703,12 +706,12 @@ __global__ void __launch_bounds__(CT_THREADS)
     cu_regs nx = ty_fetch_tile(Din, t, ncoltiles, b);
 #pragma unroll 1
     for (; b < ntiles; b += gridDim.x) {
-        const uint32_t rg = b % nrg;
-        const uint32_t cb = (b / nrg) % ncoltiles;
-        const uint32_t grp = (b / nrg) / ncoltiles;
+        const uint32_t rg = b % nrg, g = (b / nrg) & ((1u << t.lg) - 1u), bc = (b / nrg) >> t.lg;
+        const uint32_t cb = bc % ncoltiles;
+        const uint32_t grp = bc / ncoltiles;
         const uint32_t o0 = cb * W;
         const bool wrap = o0 == 0;
-        const uint64_t gbase = ((uint64_t)grp << (t.lnu + t.lus - 5)) * ROWS + (rg << (t.lrq + 2));
+        const uint64_t gbase = (((uint64_t)grp << (t.lnu + t.lus - 5)) + g) * ROWS + (rg << (t.lrq + 2));
         {
             const uint32_t i = threadIdx.x;
             lds[i] = nx.a, lds[i + CT_THREADS] = nx.b, lds[i + 2 * CT_THREADS] = nx.c, lds[i + 3 * CT_THREADS] = nx.d;
@@ -737,7 +740,7 @@ __global__ void __launch_bounds__(CT_THREADS)
             const uint32_t u = it >> (t.lrq + t.lnc);
             if (col < t.hw) continue;
             const uint32_t o = o0 + col - t.hw;
-            if (o < UW) *(u4 *)(Dout + gbase + ((uint64_t)u * UW + o) * ROWS + 4 * r) = lds[it];
+            if (o < UW) *(u4 *)(Dout + gbase + (((uint64_t)u * UW + o) << t.lg) * ROWS + 4 * r) = lds[it];
         }
         __syncthreads();
     }
@@ -1903,6 +1906,37 @@ static inline uint32_t ilog2(uint64_t x) {
 // 2^16 unit]; the last two groups commute. Taylor phases: k_conv_taylor (groups A and B, out of place), whole-unit
 // phases: inside the top butterfly pass when `units_in_top`, local phases: k_conv_tile (in place). Anything the
 // fused kernels do not cover goes through the generic one-phase kernel. Returns the buffer index of the result.
+// group A restricted to the phases pw = 2^pb_lo .. 2^pb_hi bits (5 <= pb_lo <= pb_hi <= R - 1) of an array of
+// 2^(R+16) bits per row. Its largest chunk spans 2^(pb_hi-4) units of 2^21 bits (one group); every shift is a multiple
+// of 2^(pb_lo-5) words = the column stride, so the halo is 2^(pb_hi-pb_lo+1) columns whatever R is.
+static bool make_taylor_a(uint32_t R, uint32_t pb_hi, uint32_t pb_lo, taylor_desc &t, unsigned &grid, uint32_t &ncol) {
+    memset(&t, 0, sizeof t);
+    if (pb_lo < 5 || pb_hi < pb_lo || pb_hi + 1 > R) return false;
+    int lrq = 3;
+    t.lus = 21;
+    t.lnu = pb_hi - 4;
+    t.lg = pb_lo - 5;
+    t.hw = 1u << (pb_hi - pb_lo + 1);
+    int lnc = 10 - (int)t.lnu;
+    while (lnc < 0 || (1u << lnc) < 2 * t.hw) {
+        lrq--;
+        lnc++;
+    }
+    if (lrq < 0 || t.lus - 5 - t.lg < (uint32_t)lnc) return false;
+    t.lnc = (uint32_t)lnc;
+    for (int pb = (int)pb_hi; pb >= (int)pb_lo; pb--) {
+        t.lchunk[t.nph] = (uint8_t)(pb + 17);
+        t.lpw[t.nph] = (uint8_t)pb;
+        t.nph++;
+    }
+    t.lrq = (uint32_t)lrq;
+    const uint32_t UW = 1u << (t.lus - 5 - t.lg), W = (1u << t.lnc) - t.hw;
+    ncol = (UW + W - 1) / W;
+    const uint32_t groups = 1u << (R - 5 - t.lnu);
+    grid = (groups * ncol * (32u >> t.lrq)) << t.lg;
+    return true;
+}
+
 static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid, uint32_t &ncol) {
     memset(&t, 0, sizeof t);
     int lrq = 3;
@@ -1971,7 +2005,25 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const bool fused = R >= 1 && !getenv("SOT_NO_TOP");
     const bool haveB = fused && make_taylor(R, false, tB, gB, ncB);
     const bool needA = R > 5;
-    const bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA);
+    bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA);
+    // R >= 11: one group-A tile would be half halo with 16-byte row spans (4.8 ms for one launch at R = 11, n = 2^26).
+    // Split: A2 = the phases pw >= 2^9 bits on columns 16 words apart (halo 4 columns), then A = the R = 9 tile
+    // geometry (pw = 2^8 .. 2^5) on groups of 16 units: 1.1 ms each. (At R = 10 the split measures the same as the
+    // single tile with 32-byte spans, so it keeps one launch.)
+    taylor_desc tA2;
+    unsigned gA2 = 0;
+    uint32_t ncA2 = 0;
+    bool haveA2 = false;
+    if (haveA && R >= 11 && !getenv("SOT_NO_ASPLIT")) {
+        taylor_desc lo, hi;
+        unsigned glo = 0, ghi = 0;
+        uint32_t nlo = 0, nhi = 0;
+        if (make_taylor_a(R, 8, 5, lo, glo, nlo) && make_taylor_a(R, R - 1, 9, hi, ghi, nhi)) {
+            tA = lo, gA = glo, ncA = nlo;
+            tA2 = hi, gA2 = ghi, ncA2 = nhi;
+            haveA2 = true;
+        }
+    }
     const bool fusedT = haveB && (!needA || haveA);
     auto generic = [&](const std::vector<phase_t> &v) {
         for (size_t q = 0; q < v.size(); q++) {
@@ -2006,6 +2058,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     };
     if (!inverse) {
         if (fusedT) {
+            if (haveA2) run_taylor(tA2, gA2, ncA2);
             if (haveA) run_taylor(tA, gA, ncA);
             run_taylor(tB, gB, ncB);
         } else {
@@ -2025,6 +2078,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         if (fusedT) {
             run_taylor(tB, gB, ncB);
             if (haveA) run_taylor(tA, gA, ncA);
+            if (haveA2) run_taylor(tA2, gA2, ncA2);
         } else {
             generic(taylor);
         }
