@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void bfly_item(const uint32_t *lds, uint32_t xs, uint
     }
 }
 
-template <bool INV>
+template <bool INV, int WAVES = TL_WAVES>
 __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, uint32_t base_w,
                                             const uint32_t *__restrict__ TW, uint32_t wave, uint32_t lane) {
     for (uint32_t qi = 0; qi < d.nlev; qi++) {
@@ -1017,7 +1017,7 @@ __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, u
         const uint32_t lnch = K > 8 ? np - 3 : 0;  // log2(output chunks per butterfly)
         const uint32_t nitems = (1u << (d.nb - 1 - np)) << lnch;
         const uint32_t NO = K < 8 ? K : 8;
-        for (uint32_t it0 = 0; it0 < nitems; it0 += TL_WAVES) {
+        for (uint32_t it0 = 0; it0 < nitems; it0 += WAVES) {
             const uint32_t it = it0 + wave;
             const bool act = it < nitems;
             uint32_t xn[8], yn[8];
@@ -1097,6 +1097,102 @@ __global__ void __launch_bounds__(TL_THREADS)
     tile_levels<INV>(lds, d, base_w, TW, wave, lane);
     if (INV && up.nsteps) tile_unit_phases(lds, up, up.list);
     tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
+}
+
+// The extra 32-plane word-level passes of m >= 26 (one or two levels over the whole array): a 128-slot tile for BOTH
+// row halves in a workgroup of 8 waves. A wave owns one work item (butterfly x 8 output planes) of a level and applies
+// it to rows 0..63 and rows 64..127 with the SAME scalar masks: these levels are bound by the scalar unit (one
+// s_bfe_i32 per XAND), so sharing the masks between the row halves halves their cost; the workgroup also touches whole
+// 512-B granules. 64 KiB of LDS and 8 waves: two workgroups per CU overlap each other's loads and stores.
+#define W32_THREADS 512
+template <bool INV>
+__device__ __forceinline__ void w32_item(const uint32_t *l0, const uint32_t *l1, uint32_t xs, uint32_t ys,
+                                         const uint32_t *__restrict__ TW, uint32_t q, uint32_t c0, uint32_t lane,
+                                         uint32_t xn0[8], uint32_t yn0[8], uint32_t xn1[8], uint32_t yn1[8]) {
+    uint32_t rows[8];
+    tw_rows<8>(TW, q, c0, rows);
+    uint32_t y0[32], y1[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        y0[j] = l0[(ys + j) * TL_ROWS + lane];
+        y1[j] = l1[(ys + j) * TL_ROWS + lane];
+    }
+    if (INV) {
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            y0[j] ^= l0[(xs + j) * TL_ROWS + lane];
+            y1[j] ^= l1[(xs + j) * TL_ROWS + lane];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        xn0[kk] = l0[(xs + c0 + kk) * TL_ROWS + lane];
+        xn1[kk] = l1[(xs + c0 + kk) * TL_ROWS + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const uint32_t mk = 0u - ((rows[kk] >> j) & 1u);
+            xn0[kk] = XAND(xn0[kk], y0[j], mk);
+            xn1[kk] = XAND(xn1[kk], y1[j], mk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // y chunk: re-read (dynamic register indexing would spill)
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        const uint32_t a0 = l0[(ys + c0 + kk) * TL_ROWS + lane], a1 = l1[(ys + c0 + kk) * TL_ROWS + lane];
+        if (INV) {
+            yn0[kk] = a0 ^ l0[(xs + c0 + kk) * TL_ROWS + lane];
+            yn1[kk] = a1 ^ l1[(xs + c0 + kk) * TL_ROWS + lane];
+        } else {
+            yn0[kk] = a0 ^ xn0[kk];
+            yn1[kk] = a1 ^ xn1[kk];
+        }
+    }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(W32_THREADS)
+    k_tile_fft_pair(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW) {
+    __shared__ uint32_t lds2[2][(1 << 7) * TL_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *l0 = lds2[0], *l1 = lds2[1];
+    const uint32_t base_w = tile_base(d, blockIdx.x);
+    tile_load<7, 8>(l0, Z, d, base_w, 0, wave, lane);
+    tile_load<7, 8>(l1, Z, d, base_w, 1, wave, lane);
+    __syncthreads();
+    // d.nb == 7 and every level has 32 planes (np = 5, none pruned): 2 butterflies x 4 output chunks = 8 items
+    for (uint32_t qi = 0; qi < d.nlev; qi++) {
+        const uint32_t lv = d.lev[INV ? d.nlev - 1 - qi : qi];
+        const uint32_t r = lv & 255u, tbit = (lv >> 8) & 255u;
+        uint32_t bf = wave >> 2;
+        const uint32_t c0 = (wave & 3u) << 3;
+        uint32_t sl = 0;
+        for (uint32_t j = 5; j < 7; j++)
+            if (j != tbit) {
+                sl |= (bf & 1u) << j;
+                bf >>= 1;
+            }
+        const uint32_t xs = sl, ys = sl | (1u << tbit);
+        const uint32_t w = base_w | tile_word(d, sl);
+        const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
+        uint32_t xn0[8], yn0[8], xn1[8], yn1[8];
+        w32_item<INV>(l0, l1, xs, ys, TW, q, c0, lane, xn0, yn0, xn1, yn1);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            l0[(xs + c0 + kk) * TL_ROWS + lane] = xn0[kk];
+            l0[(ys + c0 + kk) * TL_ROWS + lane] = yn0[kk];
+            l1[(xs + c0 + kk) * TL_ROWS + lane] = xn1[kk];
+            l1[(ys + c0 + kk) * TL_ROWS + lane] = yn1[kk];
+        }
+        __syncthreads();
+    }
+    tile_store<7, 8>(l0, Z, d, base_w, 0, wave, lane);
+    tile_store<7, 8>(l1, Z, d, base_w, 1, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2232,11 +2328,11 @@ static fft_plan make_plan(uint32_t m) {
         if (cnt > 4) cnt = 4;
         std::vector<uint32_t> lv;
         for (uint32_t k = 0; k < cnt; k++) lv.push_back(r + k);
-        // 5 plane bits + cnt level bits are only 2^(5+cnt) slots: fill the tile up to 2^8 slots with the lowest word
-        // bits (independent batches below every level bit, so the twiddles do not depend on them): 16 work items
-        // per level = one per wave, and neighbouring 512-B granules per tile
+        // 5 plane bits + cnt level bits are only 2^(5+cnt) slots: fill the tile up to 2^7 slots with the lowest word
+        // bits (independent batches below every level bit, so the twiddles do not depend on them): 8 work items per
+        // level = one per wave of a row half in k_tile_fft_pair
         std::vector<uint32_t> batch;
-        for (uint32_t b = 0; 5 + cnt + batch.size() < 8 && !getenv("SOT_W32_SMALL"); b++) batch.push_back(b);
+        for (uint32_t b = 0; 5 + cnt + batch.size() < (getenv("SOT_NO_W32PAIR") ? 8u : 7u); b++) batch.push_back(b);
         p.w32.push_back(make_desc(m, {1, 2, 4, 8, 16}, lv, batch));
         r += cnt;
     }
@@ -2277,6 +2373,21 @@ static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, ui
     }
 }
 
+static void launch_w32(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32_t *Z, const unit_phases &up_none) {
+    bool all32 = d.nb == 7;
+    for (uint32_t l = 0; l < d.nlev; l++)
+        if (((d.lev[l] >> 16) & 255u) != 5 || (d.lev[l] >> 24)) all32 = false;
+    if (!all32) {
+        launch_tile(c, kid, inv, d, Z, up_none);
+        return;
+    }
+    const dim3 g(tile_grid(d) / 2), b(W32_THREADS);
+    if (inv)
+        SOT_LAUNCH(c, kid, (k_tile_fft_pair<true>), g, b, Z, d, c->TW);
+    else
+        SOT_LAUNCH(c, kid, (k_tile_fft_pair<false>), g, b, Z, d, c->TW);
+}
+
 static void launch_top(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32_t *Z, const unit_phases &up) {
     const uint32_t nt = tile_grid(d);
     const dim3 g(nt < c->num_cus ? nt : c->num_cus), b(TL_THREADS);
@@ -2306,12 +2417,12 @@ static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int up
         SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
     if (upto >= 3) {
         SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
-        for (auto &d : p.w32) launch_tile(c, KID_FFT_MID, false, d, Z, p.up_none);
+        for (auto &d : p.w32) launch_w32(c, KID_FFT_MID, false, d, Z, p.up_none);
     }
 }
 
 static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
-    for (size_t i = p.w32.size(); i-- > 0;) launch_tile(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
+    for (size_t i = p.w32.size(); i-- > 0;) launch_w32(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
     SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
     SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
     launch_top(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
