@@ -120,6 +120,9 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
         eng1.close()
 
 
+VALU_BITOP3_PEAK = 8.0e11  # measured: tools_micro/valu_rate.hip, profiles/r1_valu_issue_rates.txt
+
+
 def load_pmc():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
     the profiler on itself; tools_profile.sh + tools_prof_summary.py produce profiles/pmc_latest.json)."""
@@ -285,6 +288,14 @@ def main():
             if pmc:
                 out["roofline"]["traffic"] = pmc.get("dominant_traffic_bytes_per_launch")
                 out["roofline"]["traffic_note"] = pmc.get("note")
+                if pmc.get("valu_insts_per_launch") and n == 1 << 24:
+                    # what actually bounds the dominant kernel: VALU issue. Wave-instructions per
+                    # launch (PMC SQ_INSTS_VALU, same committed pass) / measured launch time, against the measured
+                    # chip-wide ceiling for v_bitop3_b32 with three VGPR operands (profiles/r1_valu_issue_rates.txt)
+                    rate = pmc["valu_insts_per_launch"] / (out["roofline"]["kernel_avg_ms"] * 1e-3)
+                    out["roofline"]["dominant_kernel_valu_issue"] = {
+                        "achieved": rate, "peak": VALU_BITOP3_PEAK, "unit": "wave-instructions/s",
+                        "frac": rate / VALU_BITOP3_PEAK}
             out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(),
                                                                                 key=lambda kv: -kv[1][0])}
         if args.lut_log2b and world == 1 and 247 << args.lut_log2b <= n:

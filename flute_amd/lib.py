@@ -42,6 +42,14 @@ def load_library():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise SotError("libflute_sot.so is missing: run `make -C flute_amd/csrc` (or __graft_entry__.build())")
+    # PyTorch-ROCm ships its own libamdhip64, and the first HIP runtime a process loads serves every later user. If this
+    # library pulled in /opt/rocm's first, a later `import torch` would find "No HIP GPUs" (seen when a test touched
+    # torch only after the engine). So when torch is installed, let it load its runtime first; without torch the
+    # library runs on the system runtime alone.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.sot_last_error.restype = C.c_char_p

@@ -64,7 +64,7 @@ def test_transpose128_on_gpu(fa, orc):
 
 
 # ------------------------------------------------------------------ stage by stage
-@pytest.mark.parametrize("n,T,seed", [(1000, 2, 42), (1000, 1, 7), (40000, 4, 3), (1 << 16, 5, 11)])
+@pytest.mark.parametrize("n,T,seed", [(1000, 2, 42), (1000, 1, 7), (40000, 4, 3), (1 << 16, 5, 11), (1, 2, 5), (129, 3, 6)])
 def test_pipeline_stages_match_oracle(fa, orc, n, T, seed):
     conf, msg2, msg, choices, delta, prg = _inputs(orc, n, seed)
     eng = fa.Engine(n)
