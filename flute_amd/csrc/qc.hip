@@ -792,29 +792,25 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             const uint32_t pi = inverse ? ph.nph - 1 - q : q;
             const uint32_t lchunk = ph.lchunk[pi], lpw = ph.lpw[pi];
             const uint32_t half = 1u << (lchunk - 1), pw = 1u << lpw, Dd = half - pw;
-            for (int step = 0; step < 2; step++) {
-                const bool fold = inverse ? step == 1 : step == 0;  // forward: fold then shift; inverse: shift then fold
-                if (fold) {
-                    // H[j] ^= H[j + D], j < pw, in every chunk
-                    const uint32_t n_it = (1u << (ph.nub - lchunk + lpw)) * 4;
-                    for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
-                        const uint32_t r = it & 3, w = it >> 2, c = w >> lpw, j = w & (pw - 1);
-                        const uint32_t dst = (c << lchunk) + half + j;
-                        lds[dst * 4 + r] ^= lds[(dst + Dd) * 4 + r];
+            // fold (H[j] ^= H[j + D], j < pw) and shift (lo[pw + j] ^= H[j], j < D) of a phase in ONE hazard-free step:
+            // the thread that owns index j does both (forward: fold first, inverse: shift first). H[j + D], j < pw,
+            // lies in [half - pw, half) of H, which no thread writes; H[j] and lo[pw + j] are touched by j's owner
+            // only. One barrier per phase instead of two.
+            const uint32_t n_it = (1u << (ph.nub - 1)) * 4;
+            for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
+                const uint32_t r = it & 3, w = it >> 2, c = w >> (lchunk - 1), j = w & (half - 1);
+                if (j < Dd) {
+                    const uint32_t base = c << lchunk;
+                    u4 h = lds[(base + half + j) * 4 + r];
+                    if (j < pw) {
+                        const u4 g = lds[(base + half + j + Dd) * 4 + r];
+                        if (!inverse) h ^= g;
+                        lds[(base + half + j) * 4 + r] = inverse ? h ^ g : h;
                     }
-                } else {
-                    // lo[pw + j] ^= H[j], j < D: enumerate j over [0, half) and skip j >= D
-                    const uint32_t n_it = (1u << (ph.nub - 1)) * 4;
-                    for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
-                        const uint32_t r = it & 3, w = it >> 2, c = w >> (lchunk - 1), j = w & (half - 1);
-                        if (j < Dd) {
-                            const uint32_t base = c << lchunk;
-                            lds[(base + pw + j) * 4 + r] ^= lds[(base + half + j) * 4 + r];
-                        }
-                    }
+                    lds[(base + pw + j) * 4 + r] ^= h;
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
         {
             const uint32_t o = t >> 3, rg = t & 7;
