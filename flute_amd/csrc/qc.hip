@@ -468,7 +468,7 @@ __device__ __forceinline__ void reg_phases(T w[8]) {
 struct move_list {
     uint32_t nsteps;
     uint32_t step_end[UP_MAX_STEPS];
-    const uint32_t *list;  // dst | src << 16 (sub-unit indices)
+    const uint32_t *list;  // PH_ENTRY words (sub-unit indices): one step per phase
 };
 // INV: thread owns sub-unit su (8 consecutive words) x row quad; forward: words su, su + 256, ...
 // (eight named registers, not an array: as a loop-carried array the prefetched tile ends up in scratch memory)
@@ -546,9 +546,16 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8) {
                 uint32_t start = 0;
                 for (uint32_t st = 0; st < mv.nsteps; st++) {
                     const uint32_t end = mv.step_end[st];
-                    for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {
-                        const uint32_t pr = mvl[it];
-                        lds[36 * (pr & 0xffffu) + x] ^= lds[36 * (pr >> 16) + x];
+                    for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {  // entries: see PH_ENTRY
+                        const uint32_t e = mvl[it];
+                        const uint32_t a = 36 * (e & 1023u) + x, c = 36 * ((e >> 10) & 1023u) + x;
+                        u4 h = lds[a];
+                        if (e >> 30) {
+                            const u4 gg = lds[36 * ((e >> 20) & 1023u) + x];
+                            if (!INV) h ^= gg;
+                            lds[a] = INV ? h ^ gg : h;
+                        }
+                        lds[c] ^= h;
                     }
                     start = end;
                     __syncthreads();
@@ -1060,9 +1067,16 @@ __device__ __forceinline__ void tile_levels(uint32_t *lds, const tile_desc &d, u
 struct unit_phases {
     uint32_t nsteps;
     uint32_t step_end[UP_MAX_STEPS];  // list index one past the last move of step s
-    const uint32_t *list;             // device memory: dst | src << 16
+    const uint32_t *list;             // device memory: PH_ENTRY words
 };
 
+// A list entry is one index j of a phase with BOTH of its operations, run by the same 16-lane group (see PH_ENTRY):
+// forward  h = L[a]; if (fold) { h ^= L[b]; L[a] = h; }  L[c] ^= h      (fold, then shift)
+// inverse  h = L[a]; L[c] ^= h; if (fold) L[a] = h ^ L[b]              (shift, then fold)
+// a = H[j], b = H[j + D] (read only in this phase), c = lo[pw + j]: no other entry of the phase touches a or c, so a
+// phase is ONE hazard-free step (one barrier), not two.
+#define PH_ENTRY(a, c, b, fold) ((a) | ((c) << 10) | ((b) << 20) | ((fold) ? 1u << 30 : 0u))
+template <bool INV>
 __device__ __forceinline__ void tile_unit_phases(uint32_t *lds, const unit_phases &up, const uint32_t *list) {
     u4 *l4 = (u4 *)lds;
     const uint32_t rq = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -1070,8 +1084,15 @@ __device__ __forceinline__ void tile_unit_phases(uint32_t *lds, const unit_phase
     for (uint32_t st = 0; st < up.nsteps; st++) {
         const uint32_t end = up.step_end[st];
         for (uint32_t it = start + g; it < end; it += TL_THREADS / 16) {
-            const uint32_t pr = list[it];
-            l4[(pr & 0xffffu) * 16 + rq] ^= l4[(pr >> 16) * 16 + rq];
+            const uint32_t e = list[it];
+            const uint32_t a = (e & 1023u) * 16 + rq, c = ((e >> 10) & 1023u) * 16 + rq, b = ((e >> 20) & 1023u) * 16 + rq;
+            u4 h = l4[a];
+            if (e >> 30) {
+                const u4 gg = l4[b];
+                if (!INV) h ^= gg;
+                l4[a] = INV ? h ^ gg : h;
+            }
+            l4[c] ^= h;
         }
         start = end;
         __syncthreads();
@@ -1089,9 +1110,9 @@ __global__ void __launch_bounds__(TL_THREADS)
     const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
     tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
-    if (!INV && up.nsteps) tile_unit_phases(lds, up, up.list);
+    if (!INV && up.nsteps) tile_unit_phases<false>(lds, up, up.list);
     tile_levels<INV>(lds, d, base_w, TW, wave, lane);
-    if (INV && up.nsteps) tile_unit_phases(lds, up, up.list);
+    if (INV && up.nsteps) tile_unit_phases<true>(lds, up, up.list);
     tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
 }
 
@@ -1437,9 +1458,9 @@ __global__ void __launch_bounds__(TL_THREADS)
             const uint32_t nidx = idx + gridDim.x < ntiles ? idx + gridDim.x : idx;
             v = tile_fetch<NB>(Z, d, tile_base(d, nidx >> 1), nidx & 1, wave, lane);
         }
-        if (!INV && up.nsteps) tile_unit_phases(lds, up, mvl);
+        if (!INV && up.nsteps) tile_unit_phases<false>(lds, up, mvl);
         top_levels<INV>(lds, d.nb, TW, wave, lane);
-        if (INV && up.nsteps) tile_unit_phases(lds, up, mvl);
+        if (INV && up.nsteps) tile_unit_phases<true>(lds, up, mvl);
         tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
         __syncthreads();
     }
@@ -2264,19 +2285,17 @@ static fft_plan make_plan(uint32_t m) {
             for (size_t q = 0; q < ph.size(); q++) {
                 const phase_t &f = inv ? ph[ph.size() - 1 - q] : ph[q];
                 const uint32_t D = (uint32_t)(f.half - f.pw), nchunks = (1u << nub_act) / (uint32_t)f.chunk;
-                for (int step = 0; step < 2; step++) {
-                    const bool fold = inv ? step == 1 : step == 0;  // forward: fold then shift; inverse: shift then fold
-                    const uint32_t per = fold ? (uint32_t)f.pw : D;
-                    for (uint32_t cidx = 0; cidx < nchunks; cidx++)
-                        for (uint32_t jj = 0; jj < per; jj++)
-                            for (uint32_t b = 0; b < (1u << nbb); b++) {
-                                const uint32_t base = cidx * (uint32_t)f.chunk;
-                                const uint32_t dst = fold ? base + (uint32_t)f.half + jj : base + (uint32_t)f.pw + jj;
-                                const uint32_t src = fold ? base + (uint32_t)f.half + jj + D : base + (uint32_t)f.half + jj;
-                                list.push_back(slot(dst, b) | (slot(src, b) << 16));
-                            }
-                    u.step_end[u.nsteps++] = (uint32_t)list.size();
-                }
+                // one step per phase: entry j < D carries the shift lo[pw + j] ^= H[j] and, for j < pw, the fold
+                // H[j] ^= H[j + D] (tile_unit_phases)
+                for (uint32_t cidx = 0; cidx < nchunks; cidx++)
+                    for (uint32_t jj = 0; jj < D; jj++)
+                        for (uint32_t b = 0; b < (1u << nbb); b++) {
+                            const uint32_t base = cidx * (uint32_t)f.chunk;
+                            const uint32_t h = base + (uint32_t)f.half + jj, lo = base + (uint32_t)f.pw + jj;
+                            const bool fold = jj < (uint32_t)f.pw;
+                            list.push_back(PH_ENTRY(slot(h, b), slot(lo, b), fold ? slot(h + D, b) : 0u, fold));
+                        }
+                u.step_end[u.nsteps++] = (uint32_t)list.size();
             }
             if (list.size() > TOP_MAX_MOVES) abort();  // 3328 at m = 25, the largest m with the units in the top pass
         }
@@ -2292,18 +2311,14 @@ static fft_plan make_plan(uint32_t m) {
         for (size_t q = 0; q < ph.size(); q++) {
             const phase_t &f = inv ? ph[ph.size() - 1 - q] : ph[q];
             const uint32_t D = (uint32_t)(f.half - f.pw), nchunks = 256u / (uint32_t)f.chunk;
-            for (int step = 0; step < 2; step++) {
-                const bool fold = inv ? step == 1 : step == 0;
-                const uint32_t per = fold ? (uint32_t)f.pw : D;
-                for (uint32_t cidx = 0; cidx < nchunks; cidx++)
-                    for (uint32_t jj = 0; jj < per; jj++) {
-                        const uint32_t base = cidx * (uint32_t)f.chunk;
-                        const uint32_t dst = fold ? base + (uint32_t)f.half + jj : base + (uint32_t)f.pw + jj;
-                        const uint32_t src = fold ? base + (uint32_t)f.half + jj + D : base + (uint32_t)f.half + jj;
-                        list.push_back(dst | (src << 16));
-                    }
-                u.step_end[u.nsteps++] = (uint32_t)list.size();
-            }
+            for (uint32_t cidx = 0; cidx < nchunks; cidx++)
+                for (uint32_t jj = 0; jj < D; jj++) {
+                    const uint32_t base = cidx * (uint32_t)f.chunk;
+                    const uint32_t h = base + (uint32_t)f.half + jj, lo = base + (uint32_t)f.pw + jj;
+                    const bool fold = jj < (uint32_t)f.pw;
+                    list.push_back(PH_ENTRY(h, lo, fold ? h + D : 0u, fold));
+                }
+            u.step_end[u.nsteps++] = (uint32_t)list.size();
         }
         if (list.size() > CU_MAX_MOVES || u.nsteps == 0) abort();  // a constant of the algorithm, not of the input
     }
