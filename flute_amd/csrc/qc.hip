@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(CT_THREADS)
 // ------------------------------------------------------------------------------------------------
 // K2w: the whole-unit phases (chunk and pw multiples of a 2^16 unit) when the top butterfly pass cannot host them
 // (m >= 26: more unit-index bits than its tile has). They only XOR granules that sit at the same offset of different
-// units, so a tile = ALL 2^nub units x one word offset x 16 rows (64 B per unit, 128 KiB at nub = 11) takes every
+// units, so a tile = ALL 2^nub units x one word offset x 16 .. 128 rows (64 B per unit at nub = 11, 128 KiB) takes every
 // phase in one HBM round trip, in place; before, each phase was a pass of k_conv_phase over the whole array (85 ms
 // of a 155 ms step at n = 2^26). Persistent with next-tile prefetch like k_conv_unit.
 struct wu_phases {
@@ -764,15 +764,12 @@ struct wu_phases {
     uint32_t nph;
     uint8_t lchunk[32], lpw[32];  // log2 of chunk and pw in units; half = chunk / 2
 };
-__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t nub, uint32_t tile) {
-    const uint32_t o = tile >> 3, rg = tile & 7;
-    const uint32_t items = 4u << nub;
-    const uint32_t *g = D + (uint64_t)o * ROWS + rg * CT_ROWS;
-    auto ld = [&](uint32_t it) {
-        u4 v = {0, 0, 0, 0};
-        if (it < items) v = ld_u4(g + (uint64_t)(it >> 2) * 2048 * ROWS + 4 * (it & 3));
-        return v;
-    };
+// tile = all 2^nub units x one word offset x 2^lq row quads, lq = 13 - nub (4 quads = 64 B per unit at nub = 11, the
+// whole 512-B granule at nub = 8): always 8192 u4 = 128 KiB, [unit][quad]
+__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t lq, uint32_t tile) {
+    const uint32_t o = tile >> (5 - lq), rg = tile & ((32u >> lq) - 1u);
+    const uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
+    auto ld = [&](uint32_t it) { return ld_u4(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & ((1u << lq) - 1u))); };
     cu_regs x;
     const uint32_t i = threadIdx.x;
     x.a = ld(i), x.b = ld(i + CT_THREADS), x.c = ld(i + 2 * CT_THREADS), x.d = ld(i + 3 * CT_THREADS);
@@ -781,10 +778,11 @@ __device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint
 }
 __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__restrict__ D, wu_phases ph, int inverse) {
     __shared__ u4 lds[8192];  // [unit][quad]
-    const uint32_t ntiles = 2048 * 8, items = 4u << ph.nub;
+    const uint32_t lq = 13 - ph.nub, qm = (1u << lq) - 1u;  // 8 <= nub <= 11 (run_conversion)
+    const uint32_t ntiles = 2048u << (5 - lq);
     uint32_t t = blockIdx.x;
     if (t >= ntiles) return;
-    cu_regs nx = wu_fetch(D, ph.nub, t);
+    cu_regs nx = wu_fetch(D, lq, t);
 #pragma unroll 1
     for (; t < ntiles; t += gridDim.x) {
         {
@@ -794,7 +792,7 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             lds[i + 7 * CT_THREADS] = nx.h;
         }
         __syncthreads();
-        nx = wu_fetch(D, ph.nub, t + gridDim.x < ntiles ? t + gridDim.x : t);
+        nx = wu_fetch(D, lq, t + gridDim.x < ntiles ? t + gridDim.x : t);
         for (uint32_t q = 0; q < ph.nph; q++) {
             const uint32_t pi = inverse ? ph.nph - 1 - q : q;
             const uint32_t lchunk = ph.lchunk[pi], lpw = ph.lpw[pi];
@@ -803,27 +801,26 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             // the thread that owns index j does both (forward: fold first, inverse: shift first). H[j + D], j < pw,
             // lies in [half - pw, half) of H, which no thread writes; H[j] and lo[pw + j] are touched by j's owner
             // only. One barrier per phase instead of two.
-            const uint32_t n_it = (1u << (ph.nub - 1)) * 4;
-            for (uint32_t it = threadIdx.x; it < n_it; it += CT_THREADS) {
-                const uint32_t r = it & 3, w = it >> 2, c = w >> (lchunk - 1), j = w & (half - 1);
+            for (uint32_t it = threadIdx.x; it < 4096; it += CT_THREADS) {  // half of the units x 2^lq quads
+                const uint32_t r = it & qm, w = it >> lq, c = w >> (lchunk - 1), j = w & (half - 1);
                 if (j < Dd) {
                     const uint32_t base = c << lchunk;
-                    u4 h = lds[(base + half + j) * 4 + r];
+                    u4 h = lds[((base + half + j) << lq) + r];
                     if (j < pw) {
-                        const u4 g = lds[(base + half + j + Dd) * 4 + r];
+                        const u4 g = lds[((base + half + j + Dd) << lq) + r];
                         if (!inverse) h ^= g;
-                        lds[(base + half + j) * 4 + r] = inverse ? h ^ g : h;
+                        lds[((base + half + j) << lq) + r] = inverse ? h ^ g : h;
                     }
-                    lds[(base + pw + j) * 4 + r] ^= h;
+                    lds[((base + pw + j) << lq) + r] ^= h;
                 }
             }
             __syncthreads();
         }
         {
-            const uint32_t o = t >> 3, rg = t & 7;
-            uint32_t *g = D + (uint64_t)o * ROWS + rg * CT_ROWS;
-            for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS)
-                *(u4 *)(g + (uint64_t)(it >> 2) * 2048 * ROWS + 4 * (it & 3)) = lds[it];
+            const uint32_t o = t >> (5 - lq), rg = t & ((32u >> lq) - 1u);
+            uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
+            for (uint32_t it = threadIdx.x; it < 8192; it += CT_THREADS)
+                *(u4 *)(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & qm)) = lds[it];
         }
         __syncthreads();
     }
