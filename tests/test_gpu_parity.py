@@ -252,3 +252,38 @@ def test_encode_leaves_receiver_rT_untouched(fa, orc):
         assert np.array_equal(before, e.download_rT(1))
     finally:
         e.close()
+
+
+def test_calls_out_of_order_are_errors_not_garbage(fa, orc):
+    """The C ABI keeps the pipeline state per role: a stage called before the one that feeds it returns an error
+    (SotError from the mirror) instead of reading stale or unwritten HBM; after the error the context still works."""
+    from flute_amd.lib import SotError
+    n, T = 1000, 2
+    e = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(3)
+        msg2, msg, choices = fa.fake_base(e.conf, rng)
+        delta, seed = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(2))
+        with pytest.raises(SotError):
+            e.qc_encode(0)  # nothing expanded yet
+        with pytest.raises(SotError):
+            e.sender_hash(delta)  # nothing encoded yet
+        tg = e.sender_expand(msg2, delta, seed, T)
+        with pytest.raises(SotError):
+            e.sender_hash(delta)  # expanded, not encoded
+        with pytest.raises(SotError):
+            e.mt_bits(delta)  # needs both roles encoded
+        with pytest.raises(ValueError):
+            e.receiver_expand(msg, choices, tg[0][:-1], tg[1])  # TreeGrp arrays of the wrong shape
+        with pytest.raises(SotError):
+            e.sender_expand(msg2, delta, seed, 0)  # num_threads = 0
+        # the context is still usable: the full sequence gives the oracle's result
+        e.qc_encode(0)
+        s_out = e.sender_hash(delta)
+        e.receiver_expand(msg, choices, *tg)
+        e.qc_encode(1, e.points(choices))
+        r_out, ch = e.receiver_hash()
+        sel = np.unpackbits(ch.view(np.uint8), bitorder="little")[:n].astype(np.int64)
+        assert np.array_equal(s_out[np.arange(n), sel], r_out)
+    finally:
+        e.close()
