@@ -120,12 +120,12 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
         eng1.close()
 
 
-VALU_BITOP3_PEAK = 8.0e11  # measured: tools_micro/valu_rate.hip, profiles/r1_valu_issue_rates.txt
+VALU_BITOP3_PEAK = 8.0e11  # measured: tools/micro/valu_rate.hip, profiles/r1_valu_issue_rates.txt
 
 
 def load_pmc():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
-    the profiler on itself; tools_profile.sh + tools_prof_summary.py produce profiles/pmc_latest.json)."""
+    the profiler on itself; tools/profile.sh + tools/prof_summary.py produce profiles/pmc_latest.json)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             return json.load(f)

@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "sot_internal.h"
@@ -76,12 +77,14 @@ void prof_resolve(sot_ctx *c) {
 
 extern "C" int sot_prof_enable(sot_ctx *c, int on) {
     if (!c) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     prof_resolve(c);
     c->prof = on != 0;
     return SOT_OK;
 }
 extern "C" int sot_prof_reset(sot_ctx *c) {
     if (!c) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     prof_resolve(c);
     for (int i = 0; i < KID_COUNT; i++) c->prof_ms[i] = 0, c->prof_n[i] = 0;
     return SOT_OK;
@@ -90,6 +93,7 @@ extern "C" int sot_prof_kernels(void) { return KID_COUNT; }
 extern "C" const char *sot_prof_name(int id) { return id >= 0 && id < KID_COUNT ? SOT_KID_NAMES[id] : ""; }
 extern "C" int sot_prof_read(sot_ctx *c, int id, double *total_ms, uint64_t *launches) {
     if (!c || id < 0 || id >= KID_COUNT) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     prof_resolve(c);
     if (total_ms) *total_ms = c->prof_ms[id];
     if (launches) *launches = c->prof_n[id];
@@ -180,7 +184,7 @@ extern "C" void sot_ctx_destroy(sot_ctx *c) {
     qc_free(c);
     void *ptrs[] = {c->role[0].V, c->role[0].enc, c->role[1].V, c->role[1].enc, c->lvl_a, c->lvl_b, c->sums,
                     c->d_base,    c->d_choices,   c->d_tg_sums, c->d_tg_last,   c->d_rks, c->d_mt,  c->d_tmp,
-                    c->d_points};
+                    c->d_points,  c->d_chw};
     for (void *p : ptrs)
         if (p) hipFree(p);
     prof_resolve(c);
@@ -209,6 +213,15 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
     }
     sot_ctx *c = new sot_ctx();
     c->device = device;
+    {
+        static const struct {
+            const char *name;
+            uint32_t bit;
+        } sw[] = {{"SOT_NO_TOP", SOT_OPT_NO_TOP},         {"SOT_NO_ASPLIT", SOT_OPT_NO_ASPLIT},   {"SOT_NO_WU", SOT_OPT_NO_WU},
+                  {"SOT_NO_W32PAIR", SOT_OPT_NO_W32PAIR}, {"SOT_NO_GGM_TOP", SOT_OPT_NO_GGM_TOP}};
+        for (auto &e : sw)
+            if (getenv(e.name)) c->opts |= e.bit;
+    }
     c->num_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     int rc = sot_configure(n, scaler, 128, &c->conf);
     if (rc != SOT_OK) {
@@ -241,7 +254,14 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
     A(c->d_tg_sums, sot_treegrp_sums_blocks(&cf) * 16);
     A(c->d_tg_last, sot_treegrp_last_blocks(&cf) * 16);
     A(c->d_mt, 3 * nw * 8);
+    A(c->d_chw, nw * 8);
     A(c->d_points, cf.parts * 8);
+    // root PRG round keys for up to one worker per tree group (more workers than groups own no group, pprf.rs:128)
+    A(c->d_rks, c->nsets * sizeof(aes_rk));
+    if (rc == SOT_OK) c->rks_cap = c->nsets;
+    // staging for sot_download_rT / sot_qc_dual_encode_host (128 x cols Blocks) and the hashed messages (n x [Block; 2])
+    c->tmp_bytes = vblocks * 16 > cf.n * 32 ? vblocks * 16 : cf.n * 32;
+    A(c->d_tmp, c->tmp_bytes);
 #undef A
     if (rc == SOT_OK) rc = qc_init(c);
     if (rc != SOT_OK) {
@@ -260,17 +280,20 @@ extern "C" int sot_ctx_conf(const sot_ctx *c, sot_conf *out) {
 extern "C" uint64_t sot_ctx_device_bytes(const sot_ctx *c) { return c ? c->dev_bytes : 0; }
 extern "C" int sot_ctx_sync(sot_ctx *c) {
     if (!c) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     SOT_HIP(hipSetDevice(c->device));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
 extern "C" void *sot_ctx_stream(sot_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+// every entry point that takes a context holds its lock for the whole call (see sot_ctx::mu)
 #define CHECK_CTX(c)                      \
     if (!(c)) {                           \
         sot_set_error("null context");    \
         return SOT_EINVAL;                \
-    }
+    }                                     \
+    std::lock_guard<std::recursive_mutex> _lk((c)->mu)
 #define CHECK_ROLE(r)                                  \
     if ((r) != SOT_ROLE_SENDER && (r) != SOT_ROLE_RECEIVER) { \
         sot_set_error("bad role %d", (r));             \
@@ -321,6 +344,10 @@ extern "C" int sot_qc_encode(sot_ctx *c, int role, const uint64_t *points, uint6
 extern "C" int sot_download_encoded(sot_ctx *c, int role, void *blocks_out) {
     CHECK_CTX(c);
     CHECK_ROLE(role);
+    if (!blocks_out) {
+        sot_set_error("download_encoded: null output");
+        return SOT_EINVAL;
+    }
     if (!c->role[role].encoded) {
         sot_set_error("download_encoded before qc_encode");
         return SOT_ESTATE;
@@ -384,6 +411,7 @@ extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_
 
 extern "C" int sot_random_silent_send(sot_ctx *c, const void *base_ots, const void *delta, const void *seed,
                                       uint64_t num_threads, void *tg_sums_out, void *tg_last_out, void *msgs_out) {
+    CHECK_CTX(c);
     SOT_TRY(sot_sender_expand(c, base_ots, delta, seed, num_threads, tg_sums_out, tg_last_out));
     SOT_TRY(sot_qc_encode(c, SOT_ROLE_SENDER, nullptr, 0));
     if (msgs_out) SOT_TRY(sot_sender_hash(c, delta, msgs_out));
@@ -392,6 +420,7 @@ extern "C" int sot_random_silent_send(sot_ctx *c, const void *base_ots, const vo
 
 extern "C" int sot_random_silent_receive(sot_ctx *c, const void *base_ots, const uint8_t *choices, const void *tg_sums,
                                          const void *tg_last, void *msgs_out, uint64_t *choice_words_out) {
+    CHECK_CTX(c);
     SOT_TRY(sot_receiver_expand(c, base_ots, choices, tg_sums, tg_last));
     std::vector<uint64_t> pts(c->conf.parts);
     SOT_TRY(sot_receiver_points(&c->conf, choices, pts.data()));

@@ -451,7 +451,7 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     uint32_t dstart = receiver ? 1 : 0;
     // levels dstart .. d1-1 in LDS (k_ggm_top); level d1 lands in nxt. The leaf level always goes through k_ggm_level<true>.
     const uint32_t d1 = depth - 1 < GGM_TOP_MAXLVL ? depth - 1 : GGM_TOP_MAXLVL;
-    if (d1 > dstart && !getenv("SOT_NO_GGM_TOP")) {
+    if (d1 > dstart && !(c->opts & SOT_OPT_NO_GGM_TOP)) {
         if (receiver) {
             SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<true>, dim3(nsets), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
                        c->sums, c->d_base, c->d_choices, c->d_tg_sums, depth);
@@ -511,10 +511,9 @@ int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const
         memcpy(key, &lo, 8);
         aes_expand_key_host(key, &rks[t]);
     }
-    if (Teff > c->rks_cap) {
-        if (c->d_rks) hipFree(c->d_rks);
-        SOT_HIP(hipMalloc((void **)&c->d_rks, Teff * sizeof(aes_rk)));
-        c->rks_cap = Teff;
+    if (Teff > c->rks_cap) {  // cannot happen: sot_ctx_create sized d_rks for one worker per tree group
+        sot_set_error("internal: root key buffer too small");
+        return SOT_EINVAL;
     }
     SOT_HIP(hipMemcpyAsync(c->d_rks, rks.data(), Teff * sizeof(aes_rk), hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 32, hipMemcpyHostToDevice, c->stream));
@@ -570,14 +569,12 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
     return SOT_OK;
 }
 
+// the staging buffer is allocated once, in sot_ctx_create, for the largest user: no hipMalloc on any stage call
 static int ensure_tmp(sot_ctx *c, uint64_t bytes) {
     if (c->tmp_bytes >= bytes) return SOT_OK;
-    if (c->d_tmp) hipFree(c->d_tmp);
-    c->d_tmp = nullptr;
-    c->tmp_bytes = 0;
-    SOT_HIP(hipMalloc(&c->d_tmp, bytes));
-    c->tmp_bytes = bytes;
-    return SOT_OK;
+    sot_set_error("internal: staging buffer of %llu bytes, need %llu", (unsigned long long)c->tmp_bytes,
+                  (unsigned long long)bytes);
+    return SOT_EINVAL;
 }
 
 int ggm_download_rT(sot_ctx *c, int role, void *out) {
@@ -610,6 +607,7 @@ int ggm_upload_rT(sot_ctx *c, int role, const void *rT) {
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[role].expanded = true;
     c->role[role].encoded = false;
+    c->mt_valid = false;  // the MT store no longer belongs to this context's leaves
     return SOT_OK;
 }
 
@@ -641,10 +639,10 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
     SOT_TRY(ensure_tmp(c, cf.n * 32));
     uint64_t nw = (cf.n + 63) / 64;
     SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
-                       c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_mt);
+                       c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_chw);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 16, hipMemcpyDeviceToHost, c->stream));
-    if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_chw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
@@ -671,27 +669,37 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
     return SOT_OK;
 }
 
+// one cleanup path for the stateless helpers: every allocation is freed and every HIP call checked
+struct dev_bufs {
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    int alloc(void **out, uint64_t bytes) {
+        *out = nullptr;
+        if (hipMalloc(out, bytes ? bytes : 16) != hipSuccess) {
+            sot_set_error("hipMalloc(%llu bytes) failed", (unsigned long long)bytes);
+            return SOT_ENOMEM;
+        }
+        p[n++] = *out;
+        return SOT_OK;
+    }
+    ~dev_bufs() {
+        for (int i = 0; i < n; i++) (void)hipFree(p[i]);
+    }
+};
+
 int util_transpose128(int device, const void *in, void *out, uint64_t ntiles) {
     SOT_HIP(hipSetDevice(device));
-    blk_t *din = nullptr, *dout = nullptr;
-    uint64_t bytes = ntiles * 2048;
     if (ntiles == 0) return SOT_OK;
-    SOT_HIP(hipMalloc((void **)&din, bytes));
-    if (hipMalloc((void **)&dout, bytes) != hipSuccess) {
-        hipFree(din);
-        sot_set_error("hipMalloc failed");
-        return SOT_ENOMEM;
-    }
-    hipMemcpy(din, in, bytes, hipMemcpyHostToDevice);
+    dev_bufs bufs;
+    blk_t *din = nullptr, *dout = nullptr;
+    const uint64_t bytes = ntiles * 2048;
+    SOT_TRY(bufs.alloc((void **)&din, bytes));
+    SOT_TRY(bufs.alloc((void **)&dout, bytes));
+    SOT_HIP(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_transpose_tiles, dim3(grid_for(ntiles, 1, 8192)), dim3(128), 0, 0, din, (uint64_t)1,
                        (uint64_t)128, dout, (uint64_t)1, (uint64_t)128, ntiles);
-    hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
-    hipFree(din);
-    hipFree(dout);
-    if (e != hipSuccess) {
-        sot_set_error("transpose128: %s", hipGetErrorString(e));
-        return SOT_EDEVICE;
-    }
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     return SOT_OK;
 }
 
@@ -701,35 +709,30 @@ int util_aes(int device, const void *key16, const void *in, void *out, uint64_t 
     aes_rk rk;
     memset(&rk, 0, sizeof(rk));
     if (!cr) aes_expand_key_host((const uint8_t *)key16, &rk);
+    dev_bufs bufs;
     blk_t *din = nullptr, *dout = nullptr;
     uint32_t *drk = nullptr;
-    SOT_HIP(hipMalloc((void **)&din, n * 16));
-    SOT_HIP(hipMalloc((void **)&dout, n * 16));
-    SOT_HIP(hipMalloc((void **)&drk, sizeof(rk)));
-    hipMemcpy(din, in, n * 16, hipMemcpyHostToDevice);
-    hipMemcpy(drk, &rk, sizeof(rk), hipMemcpyHostToDevice);
+    SOT_TRY(bufs.alloc((void **)&din, n * 16));
+    SOT_TRY(bufs.alloc((void **)&dout, n * 16));
+    SOT_TRY(bufs.alloc((void **)&drk, sizeof(rk)));
+    SOT_HIP(hipMemcpy(din, in, n * 16, hipMemcpyHostToDevice));
+    SOT_HIP(hipMemcpy(drk, &rk, sizeof(rk), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_aes_ecb, dim3(grid_for(n, 256, 2048)), dim3(256), 0, 0, drk, din, dout, n, cr);
-    hipError_t e = hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost);
-    hipFree(din);
-    hipFree(dout);
-    hipFree(drk);
-    if (e != hipSuccess) {
-        sot_set_error("aes: %s", hipGetErrorString(e));
-        return SOT_EDEVICE;
-    }
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost));
     return SOT_OK;
 }
 
 int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk_t *d_out, uint64_t nblocks) {
     aes_rk rk;
     aes_expand_key_host(key16, &rk);
+    dev_bufs bufs;
     uint32_t *drk = nullptr;
-    SOT_HIP(hipMalloc((void **)&drk, sizeof(rk)));
+    SOT_TRY(bufs.alloc((void **)&drk, sizeof(rk)));
     SOT_HIP(hipMemcpyAsync(drk, &rk, sizeof(rk), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_aes_ctr, dim3(grid_for(nblocks, 256, 2048)), dim3(256), 0, c->stream, drk, first, d_out,
                        nblocks);
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));
-    hipFree(drk);
+    SOT_HIP(hipStreamSynchronize(c->stream));  // before bufs frees drk
     return SOT_OK;
 }

@@ -27,7 +27,10 @@ struct sot_and_circ {
     std::vector<uint64_t> base;         // per layer: first value bit (64-aligned)
     std::vector<uint64_t> mt0;          // per layer: first MT bit it consumed (set by layer_msg)
     std::vector<uint8_t> msg_done;      // per layer: 1 = message computed, not yet evaluated
-    int64_t msg_layer = -1;             // the layer whose message d_own / e_own hold
+    std::vector<uint8_t> evaluated;     // per layer: 1 = outputs written to vals
+    int64_t msg_layer = -1;             // the layer whose message is pending (computed, not evaluated); -1: none
+    int64_t buf_layer = -1;             // the layer whose message d_own / e_own hold (stays readable for the peer until
+                                        // the next layer_msg overwrites it)
     uint64_t val_words = 0, msg_words = 0;
     uint32_t *xpos = nullptr, *ypos = nullptr;  // device: operand bit positions per gate
     uint64_t *vals = nullptr;                   // device
@@ -87,6 +90,7 @@ extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gat
                                    const uint32_t *layer_counts, const uint32_t *x_src, const uint32_t *y_src,
                                    sot_and_circ **out) {
     if (!c || !out || (n_gates && (!layer_counts || !x_src || !y_src))) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     *out = nullptr;
     uint64_t tot = 0;
     for (uint32_t l = 0; l < n_layers; l++) tot += layer_counts[l];
@@ -100,6 +104,7 @@ extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gat
     q->n_inputs = n_inputs, q->n_gates = n_gates, q->n_layers = n_layers;
     q->count.assign(layer_counts, layer_counts + n_layers);
     q->goff.resize(n_layers), q->base.resize(n_layers), q->mt0.assign(n_layers, 0), q->msg_done.assign(n_layers, 0);
+    q->evaluated.assign(n_layers, 0);
     uint64_t bit = ((uint64_t)n_inputs + 63) & ~63ull;
     uint32_t g = 0, maxc = 0;
     for (uint32_t l = 0; l < n_layers; l++) {
@@ -172,6 +177,7 @@ extern "C" void sot_and_circ_destroy(sot_and_circ *q) {
 extern "C" int sot_and_circ_set_inputs(sot_and_circ *q, const uint64_t *input_words) {
     if (!q || (!input_words && q->n_inputs)) return SOT_EINVAL;
     sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     SOT_HIP(hipSetDevice(c->device));
     SOT_HIP(hipMemsetAsync(q->vals, 0, q->val_words * 8, c->stream));
     if (q->n_inputs) {
@@ -182,14 +188,29 @@ extern "C" int sot_and_circ_set_inputs(sot_and_circ *q, const uint64_t *input_wo
         SOT_HIP(hipStreamSynchronize(c->stream));
     }
     std::fill(q->msg_done.begin(), q->msg_done.end(), 0);
+    std::fill(q->evaluated.begin(), q->evaluated.end(), 0);
     q->msg_layer = -1;
+    q->buf_layer = -1;
     return SOT_OK;
 }
 
 extern "C" int sot_and_circ_layer_msg(sot_and_circ *q, uint32_t layer, uint8_t *d_out, uint8_t *e_out) {
     if (!q || layer >= q->n_layers) return SOT_EINVAL;
     sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const uint32_t cnt = q->count[layer];
+    // the executor's order (executor.rs:120-193): one layer at a time, message then evaluation. There is ONE message
+    // buffer, so a second message while one is pending, a layer whose inputs are not evaluated yet, or a repeated
+    // layer (its triples would be consumed twice) are refused instead of computing from stale values.
+    if (q->msg_layer >= 0) {
+        sot_set_error("and_circ: layer_msg(%u) while the message of layer %lld is not evaluated yet", layer,
+                      (long long)q->msg_layer);
+        return SOT_ESTATE;
+    }
+    if (q->evaluated[layer] || (layer > 0 && !q->evaluated[layer - 1])) {
+        sot_set_error("and_circ: layer_msg(%u) out of order (layers run once each, in ascending order)", layer);
+        return SOT_ESTATE;
+    }
     if (!c->mt_valid || c->mt_rem < cnt) {
         sot_set_error("and_circ: layer %u needs %u multiplication triples, the store holds %llu", layer, cnt,
                       (unsigned long long)(c->mt_valid ? c->mt_rem : 0));
@@ -197,17 +218,20 @@ extern "C" int sot_and_circ_layer_msg(sot_and_circ *q, uint32_t layer, uint8_t *
     }
     SOT_HIP(hipSetDevice(c->device));
     const uint64_t nw = (c->conf.n + 63) / 64;
-    c->mt_rem -= cnt;  // split_off_last(cnt), executor.rs:139
-    q->mt0[layer] = c->mt_rem;
-    q->msg_done[layer] = 1;
-    q->msg_layer = layer;
+    const uint64_t mt0 = c->mt_rem - cnt;  // split_off_last(cnt), executor.rs:139
     SOT_LAUNCH(c, KID_AND_MSG, k_and_msg, dim3(lgrid(cnt)), dim3(256), q->vals, q->xpos, q->ypos, q->goff[layer], cnt,
-               c->d_mt, c->d_mt + nw, q->mt0[layer], q->d_own, q->e_own);
+               c->d_mt, c->d_mt + nw, mt0, q->d_own, q->e_own);
     SOT_HIP(hipGetLastError());
     const uint64_t nb = ((uint64_t)cnt + 7) / 8;
     if (d_out) SOT_HIP(hipMemcpyAsync(d_out, q->d_own, nb, hipMemcpyDeviceToHost, c->stream));
     if (e_out) SOT_HIP(hipMemcpyAsync(e_out, q->e_own, nb, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
+    // committed only now that the launch and the copies have succeeded
+    c->mt_rem = mt0;
+    q->mt0[layer] = mt0;
+    q->msg_done[layer] = 1;
+    q->msg_layer = layer;
+    q->buf_layer = layer;
     return SOT_OK;
 }
 
@@ -219,17 +243,20 @@ static int and_eval_launch(sot_and_circ *q, uint32_t layer, uint32_t party, cons
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     q->msg_done[layer] = 0;
+    q->evaluated[layer] = 1;
+    q->msg_layer = -1;
     return SOT_OK;
 }
 
 extern "C" int sot_and_circ_layer_eval(sot_and_circ *q, uint32_t layer, uint32_t party_id, const uint8_t *d_peer,
                                        const uint8_t *e_peer) {
     if (!q || layer >= q->n_layers || party_id > 1 || !d_peer || !e_peer) return SOT_EINVAL;
-    if (!q->msg_done[layer]) {
-        sot_set_error("and_circ: layer_eval before layer_msg");
+    sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!q->msg_done[layer] || q->msg_layer != (int64_t)layer) {
+        sot_set_error("and_circ: layer_eval(%u) without this layer's pending layer_msg", layer);
         return SOT_ESTATE;
     }
-    sot_ctx *c = q->ctx;
     SOT_HIP(hipSetDevice(c->device));
     const uint64_t nb = ((uint64_t)q->count[layer] + 7) / 8;
     SOT_HIP(hipMemsetAsync(q->d_peer, 0, q->msg_words * 8, c->stream));
@@ -243,12 +270,19 @@ extern "C" int sot_and_circ_layer_eval_peer(sot_and_circ *q, uint32_t layer, uin
     if (!q || !peer || layer >= q->n_layers || party_id > 1 || peer->n_layers != q->n_layers ||
         peer->count[layer] != q->count[layer] || peer->ctx->device != q->ctx->device)
         return SOT_EINVAL;
-    if (!q->msg_done[layer] || peer->msg_layer != (int64_t)layer) {
-        sot_set_error("and_circ: layer_eval_peer before both parties' layer_msg");
+    // both contexts: the peer's message buffers are read on this context's stream (address order: no deadlock when the
+    // two parties evaluate each other's layers from two threads)
+    sot_ctx *ca = q->ctx < peer->ctx ? q->ctx : peer->ctx, *cb = q->ctx < peer->ctx ? peer->ctx : q->ctx;
+    std::lock_guard<std::recursive_mutex> lk1(ca->mu);
+    std::lock_guard<std::recursive_mutex> lk2(cb->mu);
+    // the peer's message stays readable until ITS next layer_msg (buf_layer): it may already have evaluated this layer
+    if (!q->msg_done[layer] || q->msg_layer != (int64_t)layer || peer->buf_layer != (int64_t)layer) {
+        sot_set_error("and_circ: layer_eval_peer(%u) before both parties' layer_msg of this layer", layer);
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(q->ctx->device));
-    // the peer's message is copied out of its buffers (it may start its next layer at once)
+    // the peer's message is copied out of its buffers (it may start its next layer at once); its own stream has been
+    // synchronised by its layer_msg, so the bytes are complete
     const uint64_t nbw = (((uint64_t)q->count[layer] + 63) / 64) * 8;
     SOT_HIP(hipMemcpyAsync(q->d_peer, peer->d_own, nbw, hipMemcpyDeviceToDevice, q->ctx->stream));
     SOT_HIP(hipMemcpyAsync(q->e_peer, peer->e_own, nbw, hipMemcpyDeviceToDevice, q->ctx->stream));
@@ -258,6 +292,7 @@ extern "C" int sot_and_circ_layer_eval_peer(sot_and_circ *q, uint32_t layer, uin
 extern "C" int sot_and_circ_values(sot_and_circ *q, uint8_t *bits_out) {
     if (!q || !bits_out) return SOT_EINVAL;
     sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     SOT_HIP(hipSetDevice(c->device));
     std::vector<uint64_t> w(q->val_words);
     SOT_HIP(hipMemcpyAsync(w.data(), q->vals, q->val_words * 8, hipMemcpyDeviceToHost, c->stream));

@@ -26,7 +26,7 @@
 
 #define ROWS 128  // bit rows of a Block
 #ifndef QC_EXP
-// profiling experiments only (tools_exp.sh; results are wrong when set): 1 = k_fft_low without word levels,
+// profiling experiments only (tools/exp.sh; results are wrong when set): 1 = k_fft_low without word levels,
 // 2 = without intra-word levels, 4 = k_qc_finish without the tail sums, 8 = without the transposes, 16 = k_mid
 // without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
 #define QC_EXP 0
@@ -2112,7 +2112,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     taylor_desc tA, tB;
     unsigned gA = 0, gB = 0;
     uint32_t ncA = 0, ncB = 0;
-    const bool fused = R >= 1 && !getenv("SOT_NO_TOP");
+    const bool fused = R >= 1 && !(c->opts & SOT_OPT_NO_TOP);
     const bool haveB = fused && make_taylor(R, false, tB, gB, ncB);
     const bool needA = R > 5;
     bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA);
@@ -2124,7 +2124,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     unsigned gA2 = 0;
     uint32_t ncA2 = 0;
     bool haveA2 = false;
-    if (haveA && R >= 11 && !getenv("SOT_NO_ASPLIT")) {
+    if (haveA && R >= 11 && !(c->opts & SOT_OPT_NO_ASPLIT)) {
         taylor_desc lo, hi;
         unsigned glo = 0, ghi = 0;
         uint32_t nlo = 0, nhi = 0;
@@ -2152,7 +2152,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const uint32_t nub = ell_elems > 16 ? ell_elems - 16 : 0;
     auto whole_units = [&]() {
         if (units.empty()) return;
-        if (nub < 8 || nub > 11 || units.size() > 32 || getenv("SOT_NO_WU")) {
+        if (nub < 8 || nub > 11 || units.size() > 32 || (c->opts & SOT_OPT_NO_WU)) {
             generic(units);
             return;
         }
@@ -2246,14 +2246,14 @@ struct fft_plan {
     std::vector<tile_desc> w32;  // extra 32-plane word-level passes (m > 25), forward order
 };
 
-static fft_plan make_plan(uint32_t m) {
+static fft_plan make_plan(uint32_t m, uint32_t opts) {
     fft_plan p;
     // unit-index bits = word bits 11 .. m-6; the top pass owns word bits m-13 .. m-6
     std::vector<uint32_t> extra;
     for (uint32_t b = 11; b + 13 < m; b++) extra.push_back(b);
     memset(&p.up_none, 0, sizeof p.up_none);
     p.up_fwd = p.up_inv = p.up_none;
-    p.units_in_top = extra.size() <= 1 && !getenv("SOT_NO_TOP");
+    p.units_in_top = extra.size() <= 1 && !(opts & SOT_OPT_NO_TOP);
     if (!p.units_in_top) extra.clear();
     p.top = make_desc(m, {1, 2, 4, 8}, {1, 2, 3, 4, 5, 6, 7, 8}, extra);
     if (p.units_in_top) {
@@ -2340,7 +2340,7 @@ static fft_plan make_plan(uint32_t m) {
         // bits (independent batches below every level bit, so the twiddles do not depend on them): 8 work items per
         // level = one per wave of a row half in k_tile_fft_pair
         std::vector<uint32_t> batch;
-        for (uint32_t b = 0; 5 + cnt + batch.size() < (getenv("SOT_NO_W32PAIR") ? 8u : 7u); b++) batch.push_back(b);
+        for (uint32_t b = 0; 5 + cnt + batch.size() < ((opts & SOT_OPT_NO_W32PAIR) ? 8u : 7u); b++) batch.push_back(b);
         p.w32.push_back(make_desc(m, {1, 2, 4, 8, 16}, lv, batch));
         r += cnt;
     }
@@ -2355,6 +2355,8 @@ static inline unsigned tile_grid(const tile_desc &d) { return (unsigned)((1u << 
 static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, uint32_t *Z, const unit_phases &up_in) {
     tile_desc d = d_in;
     unit_phases up = up_in;
+#if QC_EXP  // profiling experiments only (tools/exp.sh builds with -DQC_EXP=...): these SKIP computation, so the default
+            // library must not contain them
     if (getenv("SOT_DEBUG_NOLEVELS")) d.nlev = 0;
     if (getenv("SOT_DEBUG_NOUNITS")) up.nsteps = 0;
     if (const char *e = getenv("SOT_DEBUG_POS")) {  // experiment: synthetic tile bit positions, no compute
@@ -2367,6 +2369,7 @@ static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, ui
             d.tmask |= 1u << pos;
         }
     }
+#endif
     const dim3 g(tile_grid(d)), b(TL_THREADS);
     if (d.nb <= 8) {
         if (inv)
@@ -2441,15 +2444,16 @@ static int upload_a_and_transform(sot_ctx *c) {
     const qc_geom &g = c->g;
     const uint64_t nb128 = cf.n_blocks * 128;
     // a = first n64 u64 of AesRng(seed = Block::from(1)) (quasi_cyclic_encode.rs:127-138)
-    blk_t *d_araw = nullptr;
-    SOT_HIP(hipMalloc((void **)&d_araw, cf.n_blocks * 16));
+    // the raw keystream is staged in Z0 (not yet in use; n_blocks * 16 B is far below its size)
+    blk_t *d_araw = (blk_t *)c->Z0;
+    if (cf.n_blocks * 16 > g.nw * ROWS * 4) {
+        sot_set_error("internal: a does not fit the staging buffer");
+        return SOT_EINVAL;
+    }
     uint8_t key[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int rc = util_aes_ctr_device(c, key, 0, d_araw, cf.n_blocks);
+    SOT_TRY(util_aes_ctr_device(c, key, 0, d_araw, cf.n_blocks));
     std::vector<uint32_t> a(cf.n_blocks * 4 + 2);
-    if (rc == SOT_OK && hipMemcpy(a.data(), d_araw, cf.n_blocks * 16, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = SOT_EDEVICE;
-    hipFree(d_araw);
-    SOT_TRY(rc);
+    SOT_HIP(hipMemcpy(a.data(), d_araw, cf.n_blocks * 16, hipMemcpyDeviceToHost));
     // a' = a mod (x^P - 1): fold bits [P, nb128) onto [0, nb128 - P)
     auto getbit = [&](uint64_t i) -> uint32_t { return (a[i >> 5] >> (i & 31)) & 1u; };
     const uint64_t P = cf.P;
@@ -2515,7 +2519,7 @@ int qc_init(sot_ctx *c) {
     SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 256 * 4));
     hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 256 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
     SOT_HIP(hipGetLastError());
-    fft_plan *plan = new fft_plan(make_plan(m));
+    fft_plan *plan = new fft_plan(make_plan(m, c->opts));
     c->qc_plan = plan;
     SOT_TRY(dev_alloc(c, (void **)&c->MT1, 16ull * 4 * 8 * 256 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->MT2, 256ull * 4 * 8 * 256 * 4));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -86,7 +87,22 @@ struct role_state {
     bool encoded = false;
 };
 
+// result-preserving kernel-selection switches, read from the environment ONCE at sot_ctx_create (tests compare the
+// fused kernels with the generic ones through them; none of them can skip computation)
+enum sot_opt {
+    SOT_OPT_NO_TOP = 1,      // SOT_NO_TOP: one-phase-per-launch conversion kernels, whole-unit phases outside the top pass
+    SOT_OPT_NO_ASPLIT = 2,   // SOT_NO_ASPLIT: Taylor group A as one tile geometry at R >= 11
+    SOT_OPT_NO_WU = 4,       // SOT_NO_WU: whole-unit phases through the generic kernel
+    SOT_OPT_NO_W32PAIR = 8,  // SOT_NO_W32PAIR: extra 32-plane passes one row half per workgroup
+    SOT_OPT_NO_GGM_TOP = 16  // SOT_NO_GGM_TOP: every GGM level as its own launch
+};
+
 struct sot_ctx {
+    // every sot_* entry point that takes the context holds this lock for the whole call: sender and receiver share the
+    // GGM scratch, the Z buffers and one stream, and the reference drives both directions from two threads
+    // (gmw/src/mul_triple/silent_ot.rs:87-91). Recursive: the pipeline entry points call the stage entry points.
+    std::recursive_mutex mu;
+    uint32_t opts = 0;
     int device = 0;
     uint32_t num_cus = 256;  // persistent kernels launch one workgroup per CU
     hipStream_t stream = nullptr;
@@ -118,6 +134,7 @@ struct sot_ctx {
     uint32_t *sbv = nullptr;  // receiver noise indicator: one bit per Block of V (silent_ot/mod.rs:560-574)
     // MT bits
     uint64_t *d_mt = nullptr;  // a | b | c words
+    uint64_t *d_chw = nullptr; // receiver choice words of sot_receiver_hash (kept apart from the MT store)
     bool mt_valid = false;     // set by hash_mt_bits, cleared by the next expand
     uint64_t mt_rem = 0;       // triples not yet consumed by sot_and_circ_layer_msg (taken from the END of the store)
     void *d_tmp = nullptr;     // download staging

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FLUTE_SOT_LIB: another build of the same library (profiling experiments, tools_exp.sh)
+# FLUTE_SOT_LIB: another build of the same library (profiling experiments, tools/exp.sh)
 LIB_PATH = os.environ.get("FLUTE_SOT_LIB") or os.path.join(_HERE, "libflute_sot.so")
 _LIB = None
 

@@ -121,10 +121,65 @@ def test_device_to_device_exchange_and_exhaustion(fa):
             assert prod[circ.n_inputs + j] == (prod[int(circ.x_src[j])] & prod[int(circ.y_src[j])])
         assert e0.lib.sot_mt_remaining(e0.h) == n - circ.n_gates
         # 720 triples left: a second run of layer 0 (600 gates) fits, layer 1 (800) does not
-        cs[0].set_inputs(ins[0])
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
         cs[0].layer_msg(0, download=False)
-        with pytest.raises(SotError):
+        cs[1].layer_msg(0, download=False)
+        cs[0].layer_eval_from(0, cs[1])
+        cs[1].layer_eval_from(0, cs[0])
+        rem = e0.lib.sot_mt_remaining(e0.h)
+        with pytest.raises(SotError, match="triples"):
             cs[0].layer_msg(1, download=False)
+        assert e0.lib.sot_mt_remaining(e0.h) == rem  # a refused layer consumes nothing
+    finally:
+        e0.close()
+        e1.close()
+
+
+def test_layer_calls_out_of_order_are_refused(fa):
+    """One message buffer per circuit: a second layer_msg while one is pending, an evaluation of another layer than the
+    pending one, a layer whose predecessor is not evaluated, and a repeated layer are ESTATE errors that consume no
+    triples (sot_and_circ_layer_msg / _eval); the regular order still gives the subset products afterwards."""
+    from flute_amd.lib import SotError
+    luts = [(0, 1, 2, 3), (2, 3, 4)]
+    n = 1000
+    e0, e1, _ = _two_providers(fa, n, 1, 9)
+    try:
+        circ = fa.build_setup_circuit(luts)
+        assert circ.n_layers >= 3
+        rng = np.random.default_rng(2)
+        ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+        cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((e0, e1))]
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        with pytest.raises(SotError):
+            cs[0].layer_msg(1)  # layer 0 not evaluated yet
+        m0 = cs[0].layer_msg(0)
+        rem = e0.lib.sot_mt_remaining(e0.h)
+        with pytest.raises(SotError):
+            cs[0].layer_msg(1)  # message of layer 0 still pending
+        with pytest.raises(SotError):
+            cs[0].layer_msg(0)  # twice: would consume the layer's triples again
+        with pytest.raises(SotError):
+            cs[0].layer_eval(1, *m0)  # evaluation of a layer without a pending message
+        with pytest.raises(SotError):
+            cs[0].layer_eval_from(0, cs[1])  # the peer has no message for layer 0 yet
+        assert e0.lib.sot_mt_remaining(e0.h) == rem
+        m1 = cs[1].layer_msg(0)
+        cs[0].layer_eval(0, *m1)
+        cs[1].layer_eval(0, *m0)
+        with pytest.raises(SotError):
+            cs[0].layer_eval(0, *m1)  # already evaluated
+        with pytest.raises(SotError):
+            cs[0].layer_msg(0)  # already evaluated
+        for layer in range(1, circ.n_layers):
+            cs[0].layer_msg(layer, download=False)
+            cs[1].layer_msg(layer, download=False)
+            cs[0].layer_eval_from(layer, cs[1])
+            cs[1].layer_eval_from(layer, cs[0])
+        prod = cs[0].values() ^ cs[1].values()
+        for j in range(circ.n_gates):
+            assert prod[circ.n_inputs + j] == (prod[int(circ.x_src[j])] & prod[int(circ.y_src[j])])
     finally:
         e0.close()
         e1.close()

@@ -287,3 +287,81 @@ def test_calls_out_of_order_are_errors_not_garbage(fa, orc):
         assert np.array_equal(s_out[np.arange(n), sel], r_out)
     finally:
         e.close()
+
+
+def test_two_host_threads_on_one_context(fa, orc):
+    """The reference runs both directions of one SilentMtProvider concurrently (tokio::join! of random_silent_send and
+    random_silent_receive, gmw/src/mul_triple/silent_ot.rs:87-91). Sender and receiver share GGM scratch, the transform
+    buffers and one stream, so every entry point takes the context's lock: two threads calling sot_random_silent_send
+    and sot_random_silent_receive on ONE context (ctypes releases the GIL) each get the oracle's bytes, run after run."""
+    import threading
+    n, T = 40000, 4
+    conf = orc.configure(n)
+    rng = np.random.default_rng(17)
+    x = orc.fake_base(conf, rng)  # direction X: this context sends
+    y = orc.fake_base(conf, rng)  # direction Y: this context receives
+    delta, seed, dp, sp = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    o_s, _, _, _, _ = orc.random_silent_send(conf, x[0], delta, seed, T)
+    _, y_sums, y_last = orc.pprf_sender_expand(conf, y[0], dp, sp, T)
+    o_r, o_ch, _, _ = orc.random_silent_receive(conf, y[1], y[2], y_sums, y_last)
+    oa, ob, oc = orc.mt_bits(o_s.reshape(-1, 2), o_r, o_ch)
+    eng = fa.Engine(n)
+    try:
+        snd = fa.Sender.new_with_silent_base_ots(eng, x[0], T)
+        rcv = fa.Receiver.new_with_silent_base_ots(eng, y[1], y[2], T)
+        for _ in range(3):
+            res, errs = {}, []
+
+            def send():
+                try:
+                    res["s"] = snd.random_silent_send(delta, seed)
+                except Exception as e:  # surfaced below
+                    errs.append(e)
+
+            def recv():
+                try:
+                    res["r"] = rcv.random_silent_receive((y_sums, y_last))
+                except Exception as e:
+                    errs.append(e)
+
+            th = [threading.Thread(target=send), threading.Thread(target=recv)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not errs, errs
+            assert np.array_equal(res["s"], o_s)
+            assert np.array_equal(res["r"][0], o_r) and np.array_equal(res["r"][1], o_ch)
+            a, b, c = eng.mt_bits(delta)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob) and np.array_equal(c, oc)
+    finally:
+        eng.close()
+
+
+def test_receiver_hash_leaves_the_mt_store_alone(fa, orc):
+    """sot_receiver_hash keeps its choice words in a buffer of its own: the a | b | c store of an earlier sot_mt_bits is
+    still what sot_mt_bits_to_device hands over; uploading new leaves (sot_qc_dual_encode_host) invalidates the store."""
+    import torch
+    from flute_amd.lib import SotError
+    n, T = 3000, 2
+    e = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(15)
+        x = fa.fake_base(e.conf, rng)
+        delta, seed = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(2))
+        tg = e.sender_expand(x[0], delta, seed, T)
+        e.qc_encode(0)
+        e.receiver_expand(x[1], x[2], *tg)
+        e.qc_encode(1, e.points(x[2]))
+        a, b, c = e.mt_bits(delta)
+        _, ch = e.receiver_hash()
+        assert np.array_equal(ch, a)  # a = the receiver's choice bits
+        buf = torch.zeros(e.mt_words(), dtype=torch.int64, device="cuda:0")
+        e.mt_bits_to_device(buf.data_ptr(), buf.numel() * 8)
+        assert np.array_equal(buf.cpu().numpy().view(np.uint64), np.concatenate([a, b, c]))
+        rT = rng.integers(0, 2 ** 64, size=(128, e.conf.cols, 2), dtype=np.uint64)
+        e.qc_dual_encode_host(1, rT, e.points(x[2]))
+        with pytest.raises(SotError):
+            e.mt_bits_to_device(buf.data_ptr(), buf.numel() * 8)
+    finally:
+        e.close()

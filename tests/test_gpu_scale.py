@@ -94,26 +94,28 @@ def test_full_size_properties(log2n):
 
 @pytest.mark.parametrize("log2n", [21, 22, 23])
 def test_fused_conversion_equals_generic_path(log2n, monkeypatch):
-    """The fused multi-unit conversion kernel (k_conv_top) against the one-phase-per-launch generic kernels,
-    bit for bit, at sizes where several multi-unit phases exist (check_correlated cannot see an error that
-    sender and receiver share)."""
+    """The fused multi-unit conversion kernels against the one-phase-per-launch generic kernels, bit for bit, at sizes
+    where several multi-unit phases exist (check_correlated cannot see an error that sender and receiver share). The
+    kernel-selection switches are read once, at sot_ctx_create: the generic path is a second context."""
     import flute_amd as fa
     n = 1 << log2n
-    eng = fa.Engine(n)
-    try:
-        rng = np.random.default_rng(log2n)
-        msg2, msg, choices = fa.fake_base(eng.conf, rng)
-        delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
-        seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
-        eng.sender_expand(msg2, delta, seed, 4)
-        eng.qc_encode(0)
-        fused = eng.download_encoded(0)
-        monkeypatch.setenv("SOT_NO_TOP", "1")
-        eng.qc_encode(0)
-        generic = eng.download_encoded(0)
-        assert np.array_equal(fused, generic)
-    finally:
-        eng.close()
+    rng = np.random.default_rng(log2n)
+    out = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("SOT_NO_TOP", "1")
+        eng = fa.Engine(n)
+        try:
+            if not generic:
+                msg2, msg, choices = fa.fake_base(eng.conf, rng)
+                delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+                seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+            eng.sender_expand(msg2, delta, seed, 4)
+            eng.qc_encode(0)
+            out.append(eng.download_encoded(0))
+        finally:
+            eng.close()
+    assert np.array_equal(out[0], out[1])
 
 
 def test_2pow22_encode_matches_oracle_with_reference_multiplier(orc):
@@ -137,7 +139,9 @@ def test_2pow22_encode_matches_oracle_with_reference_multiplier(orc):
         eng.close()
 
 
-def _encode_both_vs_oracle(orc, n, T, seed, receiver=True):
+def _encode_both_vs_oracle(orc, n, T, seed, receiver=True, hashes=False):
+    """Sender B, receiver A (and with `hashes` the receiver's choice words and the MT words a, b, c of the context's
+    two instances) against the oracle whose products come from the reference's bitpolymul2 when oracle/_ref exists."""
     import flute_amd as fa
     conf = orc.configure(n)
     rng = np.random.default_rng(seed)
@@ -154,17 +158,28 @@ def _encode_both_vs_oracle(orc, n, T, seed, receiver=True):
             eng.receiver_expand(msg, choices, sums, last)
             eng.qc_encode(1, pts)
             A = eng.download_encoded(1)
+            if hashes:
+                _, ch = eng.receiver_hash(download=False)
+                a, b, c = eng.mt_bits(delta)
     finally:
         eng.close()
     orc.use_reference_multiplier(True)
     try:
         o_rT, o_sums, o_last = orc.pprf_sender_expand(conf, msg2, delta, prg, T)
         assert np.array_equal(sums, o_sums) and np.array_equal(last, o_last)
-        assert np.array_equal(B, orc.qc_dual_encode(conf, o_rT))
+        o_B = orc.qc_dual_encode(conf, o_rT)
+        del o_rT
+        assert np.array_equal(B, o_B)
         if receiver:
             o_rT_r = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
             o_A, _ = orc.qc_dual_encode2(conf, o_rT_r, pts, packed=True)
+            del o_rT_r
             assert np.array_equal(A, o_A)
+            if hashes:
+                o_r, o_ch = orc.receiver_hash(o_A)
+                assert np.array_equal(ch, o_ch)
+                oa, ob, oc = orc.mt_bits(orc.sender_hash(delta, o_B).reshape(-1, 2), o_r, o_ch)
+                assert np.array_equal(a, oa) and np.array_equal(b, ob) and np.array_equal(c, oc)
     finally:
         orc.use_reference_multiplier(False)
 
@@ -175,10 +190,21 @@ def test_odd_sizes_match_oracle(orc, n, T):
     _encode_both_vs_oracle(orc, n, T, n % 9973)
 
 
-@pytest.mark.parametrize("log2n", [25, 26])
-def test_large_sender_matches_oracle(orc, log2n):
-    """2^25 and BASELINE.json's largest size 2^26 (m = 26, 27: extra 32-plane passes, whole-unit conversion phases in
-    k_conv_wholeunits instead of the top pass). Needs oracle/_ref for a tolerable oracle run time."""
+@pytest.mark.parametrize("log2n", [23, 24])
+def test_headline_size_matches_oracle(orc, log2n):
+    """n = 2^24 is the size bench.py times (transform size m = 25: k_fft_low<1,16> with nb = 9, k_top<.,9>) and n = 2^23
+    is m = 24: both roles, the receiver's choice words and the MT words, bit for bit against the oracle (silent_ot/
+    mod.rs:410-482, pprf.rs:456-535)."""
     if orc.ref_lib() is None:
         pytest.skip("oracle/_ref absent")
-    _encode_both_vs_oracle(orc, 1 << log2n, 4, log2n, receiver=False)
+    _encode_both_vs_oracle(orc, 1 << log2n, 4, 1000 + log2n, receiver=True, hashes=True)
+
+
+@pytest.mark.parametrize("log2n", [25, 26])
+def test_large_sizes_match_oracle(orc, log2n):
+    """2^25 and BASELINE.json's largest size 2^26 (m = 26, 27: extra 32-plane passes, whole-unit conversion phases in
+    k_conv_wholeunits instead of the top pass), sender AND receiver (k_recv_fix / k_recv_last at depth 20, 21 and the sb
+    substitution), choice words and MT words. Needs oracle/_ref for a tolerable oracle run time."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref absent")
+    _encode_both_vs_oracle(orc, 1 << log2n, 4, log2n, receiver=True, hashes=True)

@@ -1,4 +1,6 @@
-"""Manual check: GPU pipeline vs oracle (reference multiplier) at arbitrary n. usage: tools_check_n.py n [T]"""
+"""Manual check: GPU pipeline vs oracle (reference multiplier) at arbitrary n. usage: tools/check_n.py n [T]"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import sys, time
 import numpy as np
 import flute_amd as fa

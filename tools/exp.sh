@@ -1,7 +1,7 @@
 #!/bin/bash
-# builds experiment variants of the library into exp/ (git-ignored): tools_exp.sh "<name> <extra flags>" ...
+# builds experiment variants of the library into exp/ (git-ignored): tools/exp.sh "<name> <extra flags>" ...
 set -e
-cd "$(dirname "$0")/flute_amd/csrc"
+cd "$(dirname "$0")/../flute_amd/csrc"
 mkdir -p ../../exp
 make -s >/dev/null 2>&1
 for spec in "$@"; do

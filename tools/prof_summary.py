@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 (rocpd sqlite) outputs of tools_profile.sh into CSV files under profiles/.
+"""Summarise the rocprofv3 (rocpd sqlite) outputs of tools/profile.sh into CSV files under profiles/.
 
-  python tools_prof_summary.py gpurun_out/prof_<tag> profiles/<prefix>
+  python tools/prof_summary.py gpurun_out/prof_<tag> profiles/<prefix>
 
 Writes <prefix>_kernel_stats.csv (kernel trace: calls, total/avg/min/max ns) and <prefix>_pmc.csv (per kernel,
 per launch averages of every collected counter; FETCH_SIZE additionally x2 as MI355X_MICROARCH.md prescribes

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun): kernel trace + separate PMC passes.
-# Usage: bash tools_profile.sh <tag>   -> gpurun_out/prof_<tag>/{trace,fetch,write,sq}/...
+# Usage: bash tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/{trace,fetch,write,sq}/...
 set -o pipefail
 TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
