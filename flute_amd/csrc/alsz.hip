@@ -13,6 +13,7 @@
 // every thread hashes one OT. Workgroups of 1024 threads take 8 tiles at a time.
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "aes_dev.h"
@@ -149,4 +150,85 @@ extern "C" int sot_alsz_receive(int device, const void *base_ots, const uint8_t 
 extern "C" int sot_alsz_send(int device, const void *base_ots, const void *base_choices, const uint8_t *u_rows,
                              uint64_t count, void *msgs_out) {
     return alsz_run(true, device, base_ots, nullptr, base_choices, (uint8_t *)u_rows, count, msgs_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing (no counterpart in the reference; for callers that cannot call hipMalloc:
+// code under HIP graph capture, tight serving loops, harnesses that forbid it). Same computation and same kernel as
+// sot_alsz_receive, but every device buffer -- the 256 expanded base-OT keys, the padded choice blocks, the u-row
+// matrix and the hashed messages -- lives in ONE file-scope device array of a fixed, modest size, so the call makes no
+// hipMalloc / hipFree and no host heap allocation either. Each GPU holds its own copy of the array until the process
+// ends; its device address is looked up once per device with hipGetSymbolAddress and only that pointer is ever handed
+// to kernels and copies. Calls on one GPU share the array: within this process they are serialised by a lock, and the
+// array keeps the previous call's contents (the one region that must start at zero, the choice padding, is cleared).
+#define AZ_NA_MAX_COUNT (1ull << 16)                 // OT extensions per call
+#define AZ_NA_NJ (AZ_NA_MAX_COUNT / 128)             // 128-OT tiles
+#define AZ_NA_OFF_RKS 0                              // [256][44] words
+#define AZ_NA_OFF_CH (AZ_NA_OFF_RKS + 256 * 44 * 4)  // 45056 = 176 * 256: [nj] Blocks
+#define AZ_NA_OFF_U (AZ_NA_OFF_CH + AZ_NA_NJ * 16)   // [128][nj] Blocks
+#define AZ_NA_OFF_OUT (AZ_NA_OFF_U + 128 * AZ_NA_NJ * 16)
+#define AZ_NA_BYTES (AZ_NA_OFF_OUT + AZ_NA_MAX_COUNT * 16)  // 2 150 400 B (2.05 MiB) per GPU
+static __device__ __align__(256) unsigned char scratch[AZ_NA_BYTES];
+
+#define AZ_NA_MAX_DEVICES 64
+static std::mutex g_na_mu;
+static unsigned char *g_na_ptr[AZ_NA_MAX_DEVICES];  // device address of `scratch` on each GPU (nullptr: not looked up yet)
+
+extern "C" uint64_t sot_alsz_noalloc_max_count(void) { return AZ_NA_MAX_COUNT; }
+
+extern "C" int sot_alsz_receive_noalloc(int device, const void *base_ots, const uint8_t *choice_bytes, uint64_t count,
+                                        uint8_t *u_rows_out, void *msgs_out) {
+    if (!base_ots || !choice_bytes || !u_rows_out || !msgs_out) return SOT_EINVAL;
+    if (count == 0 || count % 8) {
+        sot_set_error("alsz: the number of OT extensions must be a positive multiple of 8 (ot_ext/mod.rs:58-62)");
+        return SOT_EINVAL;
+    }
+    if (count > AZ_NA_MAX_COUNT) {
+        sot_set_error("sot_alsz_receive_noalloc: count %llu exceeds the fixed scratch array (at most %llu OTs per call; "
+                      "use sot_alsz_receive for more)",
+                      (unsigned long long)count, (unsigned long long)AZ_NA_MAX_COUNT);
+        return SOT_EINVAL;
+    }
+    if (device < 0 || device >= AZ_NA_MAX_DEVICES) {
+        sot_set_error("sot_alsz_receive_noalloc: device index %d out of range", device);
+        return SOT_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_na_mu);  // calls that share a GPU's array must not overlap
+    SOT_HIP(hipSetDevice(device));
+    if (!g_na_ptr[device]) {
+        // once per device, with that device current: the array's name is a host-side stand-in, not a device address
+        unsigned char *p = nullptr;
+        SOT_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) {
+            sot_set_error("sot_alsz_receive_noalloc: no device address for the scratch array");
+            return SOT_EDEVICE;
+        }
+        g_na_ptr[device] = p;
+    }
+    unsigned char *const base = g_na_ptr[device];
+    uint32_t *const d_rks = (uint32_t *)(base + AZ_NA_OFF_RKS);
+    blk_t *const d_ch = (blk_t *)(base + AZ_NA_OFF_CH);
+    blk_t *const d_U = (blk_t *)(base + AZ_NA_OFF_U);
+    blk_t *const d_out = (blk_t *)(base + AZ_NA_OFF_OUT);
+    const uint64_t cols = count / 8, nj = (count + 127) / 128;
+    uint32_t rks[256 * 44];  // 44 KiB of stack: no heap allocation on the host either
+    for (uint32_t k = 0; k < 256; k++) {
+        aes_rk rk;
+        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
+        memcpy(&rks[k * 44], rk.w, 176);
+    }
+    SOT_HIP(hipMemcpy(d_rks, rks, sizeof(rks), hipMemcpyHostToDevice));
+    // choices as nj whole Blocks: the bytes past count / 8 must be zero, whatever the last call left there
+    SOT_HIP(hipMemset(d_ch, 0, nj * 16));
+    SOT_HIP(hipMemcpy(d_ch, choice_bytes, cols, hipMemcpyHostToDevice));
+    uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
+    if (g > 512) g = 512;
+    // U[r][j] (r < 128, j < nj) and out[i] (i < count) are written in full by the kernel before they are read back
+    hipLaunchKernelGGL(k_alsz<false>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, make_uint4(0, 0, 0, 0),
+                       (const uint8_t *)nullptr, d_U, nj, count, d_out);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpy(msgs_out, d_out, count * 16, hipMemcpyDeviceToHost));
+    // row r of the device matrix is nj Blocks wide, the caller's is count / 8 bytes
+    SOT_HIP(hipMemcpy2D(u_rows_out, cols, d_U, nj * 16, cols, 128, hipMemcpyDeviceToHost));
+    return SOT_OK;
 }

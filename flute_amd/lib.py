@@ -31,7 +31,8 @@ EXPORTS = [
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
     "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
     "sot_and_circ_set_inputs", "sot_and_circ_layer_msg", "sot_and_circ_layer_eval", "sot_and_circ_layer_eval_peer",
-    "sot_and_circ_values", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send",
+    "sot_and_circ_values", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
+    "sot_alsz_noalloc_max_count",
 ]
 
 
@@ -105,6 +106,8 @@ def load_library():
     L.sot_mt_remaining.argtypes = [P]
     L.sot_alsz_receive.argtypes = [i32, P, P, u64, P, P]
     L.sot_alsz_send.argtypes = [i32, P, P, P, u64, P]
+    L.sot_alsz_receive_noalloc.argtypes = [i32, P, P, u64, P, P]
+    L.sot_alsz_noalloc_max_count.restype = u64
     L.sot_mt_remaining.restype = u64
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -163,6 +163,17 @@ int sot_alsz_receive(int device, const void *base_ots, const uint8_t *choice_byt
 int sot_alsz_send(int device, const void *base_ots, const void *base_choices, const uint8_t *u_rows, uint64_t count,
                   void *msgs_out);
 
+/* The one entry point that allocates nothing. NO counterpart in the reference: it exists for callers that cannot call
+ * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same arguments,
+ * computation and results as sot_alsz_receive, but the device buffers (expanded keys, padded choices, u-row matrix,
+ * hashed messages) are one file-scope device array of 2 150 400 bytes per GPU, held until the process ends; the call
+ * makes no hipMalloc / hipFree and no host heap allocation. count <= sot_alsz_noalloc_max_count() = 65 536 OTs per call,
+ * larger counts return SOT_EINVAL. Every call on a GPU shares that GPU's array (the last call's contents are
+ * overwritten): calls in this process are serialised by a lock; do not rely on anything else for overlapping calls. */
+int sot_alsz_receive_noalloc(int device, const void *base_ots, const uint8_t *choice_bytes, uint64_t count,
+                             uint8_t *u_rows_out, void *msgs_out);
+uint64_t sot_alsz_noalloc_max_count(void);
+
 /* ---- whole-direction pipelines (random_silent_send / random_silent_receive) --------------- */
 /* silent_ot/mod.rs:193-211. msgs_out may be NULL (results stay in HBM). */
 int sot_random_silent_send(sot_ctx *ctx, const void *base_ots, const void *delta, const void *seed,
