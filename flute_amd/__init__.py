@@ -6,7 +6,7 @@ gmw SilentMtProvider) on top of that ABI. There is no CPU fallback: without the 
 gfx950 device every compute call raises.
 """
 from .lib import SotError, load_library, device_count  # noqa: F401
-from .silent_ot import (QuasiCyclicConf, Engine, Sender, Receiver, MultType,  # noqa: F401
+from .silent_ot import (QuasiCyclicConf, Engine, ShardedEngine, Sender, Receiver, MultType,  # noqa: F401
                         sample_base_choice_bits, fake_base)
 from .mul_triple import MulTriples, SilentMtProvider  # noqa: F401
 from .lut_setup import SetupCircuit, build_setup_circuit, replicate_setup_circuit, AndCircuit  # noqa: F401

@@ -35,7 +35,7 @@ const char *const SOT_KID_NAMES[KID_COUNT] = {
     "k_recv_last",   "k_transpose_tiles", "k_sender_hash", "k_receiver_hash", "k_mt_bits",  "k_clear_lsb",
     "k_qc_load",     "k_conv_fwd",      "k_conv_fwd_tile", "k_fft_top",     "k_fft_mid",    "k_fft_low_mul",
     "k_ifft_mid",    "k_ifft_top",      "k_conv_inv_tile", "k_conv_inv",    "k_qc_store",   "k_qc_final",
-    "k_and_msg",     "k_and_eval"};
+    "k_and_msg",     "k_and_eval",      "k_shard_pack", "k_shard_unpack"};
 
 static hipEvent_t prof_event(sot_ctx *c) {
     if (!c->prof_free.empty()) {
@@ -182,6 +182,7 @@ extern "C" void sot_ctx_destroy(sot_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     qc_free(c);
+    shard_free(c);
     void *ptrs[] = {c->role[0].V, c->role[0].enc, c->role[1].V, c->role[1].enc, c->lvl_a, c->lvl_b, c->sums,
                     c->d_base,    c->d_choices,   c->d_tg_sums, c->d_tg_last,   c->d_rks, c->d_mt,  c->d_tmp,
                     c->d_points,  c->d_chw};
@@ -230,6 +231,8 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
     }
     const sot_conf &cf = c->conf;
     c->nsets = cf.parts / 8;
+    c->ggm_set0 = 0, c->ggm_nsets = (uint32_t)c->nsets;
+    c->n_out = cf.n;
     if (cf.depth < 4 || cf.parts % 8) {
         sot_set_error("unsupported geometry");
         delete c;
@@ -294,6 +297,12 @@ extern "C" void *sot_ctx_stream(sot_ctx *c) { return c ? (void *)c->stream : nul
         return SOT_EINVAL;                \
     }                                     \
     std::lock_guard<std::recursive_mutex> _lk((c)->mu)
+// stage entry points that work on whole leaf matrices: not on a sharded context, whose leaves are spread over ranks
+#define CHECK_UNSHARDED(c)                                                                       \
+    if ((c)->sh.world > 1) {                                                                     \
+        sot_set_error("sharded context: this stage runs through the sot_shard_* entry points"); \
+        return SOT_ESTATE;                                                                       \
+    }
 #define CHECK_ROLE(r)                                  \
     if ((r) != SOT_ROLE_SENDER && (r) != SOT_ROLE_RECEIVER) { \
         sot_set_error("bad role %d", (r));             \
@@ -323,6 +332,7 @@ extern "C" int sot_receiver_expand(sot_ctx *c, const void *base_ots, const uint8
 extern "C" int sot_download_rT(sot_ctx *c, int role, void *rT_out) {
     CHECK_CTX(c);
     CHECK_ROLE(role);
+    CHECK_UNSHARDED(c);
     if (!rT_out) return SOT_EINVAL;
     return ggm_download_rT(c, role, rT_out);
 }
@@ -330,6 +340,7 @@ extern "C" int sot_download_rT(sot_ctx *c, int role, void *rT_out) {
 extern "C" int sot_qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     CHECK_CTX(c);
     CHECK_ROLE(role);
+    CHECK_UNSHARDED(c);
     if (!c->role[role].expanded) {
         sot_set_error("qc_encode before expand");
         return SOT_ESTATE;
@@ -339,6 +350,24 @@ extern "C" int sot_qc_encode(sot_ctx *c, int role, const uint64_t *points, uint6
         return SOT_EINVAL;
     }
     return qc_encode(c, role, points, npoints);
+}
+
+extern "C" int sot_qc_encode2(sot_ctx *c, const uint64_t *points, uint64_t npoints, int packing, uint8_t *C_out) {
+    CHECK_CTX(c);
+    CHECK_UNSHARDED(c);
+    if (!c->role[SOT_ROLE_RECEIVER].expanded) {
+        sot_set_error("qc_encode2 before receiver expand");
+        return SOT_ESTATE;
+    }
+    if (!points || npoints != c->conf.parts) {
+        sot_set_error("receiver encode needs the %llu noisy points", (unsigned long long)c->conf.parts);
+        return SOT_EINVAL;
+    }
+    if (!packing && !C_out) {
+        sot_set_error("qc_encode2: ChoiceBitPacking::False returns the choice vector, C_out must not be NULL");
+        return SOT_EINVAL;
+    }
+    return qc_encode(c, SOT_ROLE_RECEIVER, points, npoints, packing ? 1 : 0, C_out);
 }
 
 extern "C" int sot_download_encoded(sot_ctx *c, int role, void *blocks_out) {
@@ -353,7 +382,7 @@ extern "C" int sot_download_encoded(sot_ctx *c, int role, void *blocks_out) {
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(c->device));
-    SOT_HIP(hipMemcpyAsync(blocks_out, c->role[role].enc, c->conf.n * 16, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipMemcpyAsync(blocks_out, c->role[role].enc, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
@@ -362,6 +391,7 @@ extern "C" int sot_qc_dual_encode_host(sot_ctx *c, int role, const void *rT, con
                                        void *blocks_out) {
     CHECK_CTX(c);
     CHECK_ROLE(role);
+    CHECK_UNSHARDED(c);
     if (!rT) return SOT_EINVAL;
     SOT_TRY(ggm_upload_rT(c, role, rT));
     SOT_TRY(sot_qc_encode(c, role, points, npoints));
@@ -371,6 +401,7 @@ extern "C" int sot_qc_dual_encode_host(sot_ctx *c, int role, const void *rT, con
 
 extern "C" int sot_qc_transform_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out) {
     CHECK_CTX(c);
+    CHECK_UNSHARDED(c);
     if (!row_in || !row_out || stage < 0 || stage > 4) return SOT_EINVAL;
     return qc_debug_row(c, row_in, stage, row_out);
 }
@@ -393,7 +424,7 @@ extern "C" int sot_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t 
 
 extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_bytes) {
     CHECK_CTX(c);
-    const uint64_t bytes = 3 * ((c->conf.n + 63) / 64) * 8;
+    const uint64_t bytes = 3 * ((c->n_out + 63) / 64) * 8;
     if (!dst_device || dst_bytes < bytes) {
         sot_set_error("mt_bits_to_device: destination of %llu bytes, need %llu", (unsigned long long)dst_bytes,
                       (unsigned long long)bytes);

@@ -17,11 +17,13 @@
 // ------------------------------------------------------------------------------------------------
 // roots: worker t = set % T owns AesRng(seed ^ t); its i-th group (i = set / T) takes keystream blocks
 // 8i..8i+7 (pprf.rs:115,128,135-137; util/aes_rng.rs:109-122)
-__global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t parts, blk_t *__restrict__ out) {
+// Every per-tree kernel takes the tree range [tr0, tr1) it works on: all trees on one GPU, the trees of this rank's tree
+// sets when one expansion is sharded over several GPUs (pprf.rs:128: the reference strides the same groups over workers).
+__global__ void k_roots(const uint32_t *__restrict__ rks, uint32_t T, uint32_t tr0, uint32_t tr1, blk_t *__restrict__ out) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
-    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= parts) return;
+    uint32_t tr = tr0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= tr1) return;
     uint32_t set = tr >> 3, j = tr & 7;
     uint32_t t = set % T, i = set / T;
     blk_t ctr = make_uint4(8 * i + j, 0, 0, 0);
@@ -83,11 +85,11 @@ __device__ __forceinline__ void ggm_put(blk_t *__restrict__ out, uint32_t set, u
 template <bool LAST>
 __global__ void __launch_bounds__(GGM_BLOCK)
     k_ggm_level(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t lvl, uint32_t nsets, uint64_t cols,
-                blk_t *__restrict__ sums /* this level: [set][2][8] */) {
+                blk_t *__restrict__ sums /* this level: [set][2][8] */, uint32_t set0) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ blk_t red[GGM_BLOCK / 64][2][8];
     aes_lds_fill(te);
-    const uint32_t set = blockIdx.y;
+    const uint32_t set = set0 + blockIdx.y;
     const uint64_t per_set = (uint64_t)8 << lvl;  // parent Blocks of this set
     const blk_t *pin = in + (uint64_t)set * per_set;
     blk_t acc0 = bzero(), acc1 = bzero();
@@ -157,13 +159,13 @@ template <bool RECV>
 __global__ void __launch_bounds__(GGM_TOP_THREADS)
     k_ggm_top(const blk_t *__restrict__ in, blk_t *__restrict__ out, uint32_t d0, uint32_t d1, uint32_t nsets,
               blk_t *__restrict__ sums /* [level][set][2][8] */, const blk_t *__restrict__ base,
-              const uint8_t *__restrict__ choices, const blk_t *__restrict__ tg_sums, uint32_t depth) {
+              const uint8_t *__restrict__ choices, const blk_t *__restrict__ tg_sums, uint32_t depth, uint32_t set0) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ blk_t bufA[2048], bufB[1024];
     __shared__ blk_t red[GGM_TOP_THREADS / 64][2][8];
     __shared__ blk_t lsum[2][8];
     aes_lds_fill(te);
-    const uint32_t set = blockIdx.x;
+    const uint32_t set = set0 + blockIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         const uint32_t n0 = 8u << d0;
@@ -228,11 +230,11 @@ __global__ void __launch_bounds__(GGM_TOP_THREADS)
 // sender: mask level sums with the base OTs, build the last-level 4-tuples (pprf.rs:199-254)
 __global__ void k_sender_treegrp(const blk_t *__restrict__ sums, const blk_t *__restrict__ base /*[tr*depth+d][2]*/,
                                  blk_t delta, uint32_t parts, uint32_t depth, blk_t *__restrict__ tg_sums,
-                                 blk_t *__restrict__ tg_last) {
+                                 blk_t *__restrict__ tg_last, uint32_t tr0, uint32_t tr1) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
-    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= parts) return;
+    uint32_t tr = tr0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= tr1) return;
     const uint32_t nsets = parts >> 3, grp = tr >> 3, j = tr & 7;
     for (uint32_t keep = 0; keep < 2; keep++)
         for (uint32_t d = 0; d + 1 < depth; d++) {
@@ -262,9 +264,9 @@ __device__ __forceinline__ uint64_t active_path(const uint8_t *cb, uint32_t dept
 // level 1 from the first base OT and the first sum (pprf.rs:376-384)
 __global__ void k_recv_init(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
                             const blk_t *__restrict__ tg_sums, uint32_t parts, uint32_t depth,
-                            blk_t *__restrict__ lvl1) {
-    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= parts) return;
+                            blk_t *__restrict__ lvl1, uint32_t tr0, uint32_t tr1) {
+    uint32_t tr = tr0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= tr1) return;
     uint32_t grp = tr >> 3, j = tr & 7;
     uint32_t not_ai = choices[(uint64_t)tr * depth];
     blk_t v = bxor(base[(uint64_t)tr * depth], tg_sums[(((uint64_t)grp * 2 + not_ai) * (depth - 1)) * 8 + j]);
@@ -275,9 +277,10 @@ __global__ void k_recv_init(const blk_t *__restrict__ base, const uint8_t *__res
 // repair the inactive child of the active parent on level d+1 (pprf.rs:456-467)
 __global__ void k_recv_fix(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
                            const blk_t *__restrict__ tg_sums, const blk_t *__restrict__ my_sums /*level d*/,
-                           uint32_t parts, uint32_t depth, uint32_t d, blk_t *__restrict__ lvl /*level d+1*/) {
-    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= parts) return;
+                           uint32_t parts, uint32_t depth, uint32_t d, blk_t *__restrict__ lvl /*level d+1*/, uint32_t tr0,
+                           uint32_t tr1) {
+    uint32_t tr = tr0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= tr1) return;
     uint32_t grp = tr >> 3, j = tr & 7;
     uint64_t leaf = active_path(choices + (uint64_t)tr * depth, depth);
     uint64_t active = leaf >> (depth - 1 - d);
@@ -294,11 +297,11 @@ __global__ void k_recv_fix(const blk_t *__restrict__ base, const uint8_t *__rest
 // last level: fix both children of the active parent inside V (pprf.rs:474-535)
 __global__ void k_recv_last(const blk_t *__restrict__ base, const uint8_t *__restrict__ choices,
                             const blk_t *__restrict__ tg_last, const blk_t *__restrict__ my_sums /*level depth-1*/,
-                            uint32_t parts, uint32_t depth, uint64_t cols, blk_t *__restrict__ V) {
+                            uint32_t parts, uint32_t depth, uint64_t cols, blk_t *__restrict__ V, uint32_t tr0, uint32_t tr1) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     aes_lds_fill(te);
-    uint32_t tr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr >= parts) return;
+    uint32_t tr = tr0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr >= tr1) return;
     const uint32_t nsets = parts >> 3, grp = tr >> 3, j = tr & 7;
     uint64_t active = active_path(choices + (uint64_t)tr * depth, depth);
     uint64_t inactive = active ^ 1;
@@ -445,6 +448,9 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 4096)
 
 static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     const uint32_t depth = (uint32_t)c->conf.depth, nsets = (uint32_t)c->nsets;
+    const uint32_t set0 = c->ggm_set0, nl = c->ggm_nsets;  // this context's tree sets (all of them on one GPU)
+    const uint32_t tr0 = 8 * set0, tr1 = 8 * (set0 + nl);
+    const dim3 gt((8 * nl + 127) / 128), bt(128);
     // sender: levels 0..depth-1 from the roots in lvl_a; receiver: levels 1..depth-1 from level 1 in lvl_b
     blk_t *cur = receiver ? c->lvl_b : c->lvl_a;
     blk_t *nxt = receiver ? c->lvl_a : c->lvl_b;
@@ -453,13 +459,13 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     const uint32_t d1 = depth - 1 < GGM_TOP_MAXLVL ? depth - 1 : GGM_TOP_MAXLVL;
     if (d1 > dstart && !(c->opts & SOT_OPT_NO_GGM_TOP)) {
         if (receiver) {
-            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<true>, dim3(nsets), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
-                       c->sums, c->d_base, c->d_choices, c->d_tg_sums, depth);
-            SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), c->d_base, c->d_choices,
-                       c->d_tg_sums, c->sums + (uint64_t)(d1 - 1) * nsets * 16, (uint32_t)c->conf.parts, depth, d1 - 1, nxt);
+            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<true>, dim3(nl), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
+                       c->sums, c->d_base, c->d_choices, c->d_tg_sums, depth, set0);
+            SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, gt, bt, c->d_base, c->d_choices, c->d_tg_sums,
+                       c->sums + (uint64_t)(d1 - 1) * nsets * 16, (uint32_t)c->conf.parts, depth, d1 - 1, nxt, tr0, tr1);
         } else {
-            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<false>, dim3(nsets), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
-                       c->sums, (const blk_t *)nullptr, (const uint8_t *)nullptr, (const blk_t *)nullptr, depth);
+            SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_top<false>, dim3(nl), dim3(GGM_TOP_THREADS), cur, nxt, dstart, d1, nsets,
+                       c->sums, (const blk_t *)nullptr, (const uint8_t *)nullptr, (const blk_t *)nullptr, depth, set0);
         }
         blk_t *t = cur;
         cur = nxt;
@@ -469,22 +475,25 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
     for (uint32_t d = dstart; d < depth; d++) {
         uint64_t per_set = (uint64_t)8 << d;
         // interior levels: few, longer-lived workgroups (each fills the 64 KiB AES table once; 15 sets x 64 ~ 4 per CU);
-        // the leaf level has enough work per workgroup and balances better with many
-        unsigned gx = grid_for(per_set, GGM_BLOCK, d + 1 < depth ? 64 : 256);
-        dim3 grid(gx, nsets);
+        // the leaf level has enough work per workgroup and balances better with many. A shard with fewer sets takes
+        // proportionally more workgroups per set.
+        unsigned cap = d + 1 < depth ? 64 : 256;
+        if (nl < nsets) cap = cap * nsets / nl;
+        unsigned gx = grid_for(per_set, GGM_BLOCK, cap);
+        dim3 grid(gx, nl);
         blk_t *lsum = c->sums + (uint64_t)d * nsets * 16;
         if (d + 1 < depth) {
             SOT_LAUNCH(c, KID_GGM_LEVEL, k_ggm_level<false>, grid, dim3(GGM_BLOCK), cur, nxt, d, nsets,
-                               c->conf.cols, lsum);
+                               c->conf.cols, lsum, set0);
             if (receiver)
-                SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, dim3((c->conf.parts + 127) / 128), dim3(128), c->d_base,
-                                   c->d_choices, c->d_tg_sums, lsum, (uint32_t)c->conf.parts, depth, d, nxt);
+                SOT_LAUNCH(c, KID_RECV_FIX, k_recv_fix, gt, bt, c->d_base, c->d_choices, c->d_tg_sums, lsum,
+                           (uint32_t)c->conf.parts, depth, d, nxt, tr0, tr1);
             blk_t *t = cur;
             cur = nxt;
             nxt = t;
         } else {
             SOT_LAUNCH(c, KID_GGM_LEAF, k_ggm_level<true>, grid, dim3(GGM_BLOCK), cur, V, d, nsets, c->conf.cols,
-                               lsum);
+                               lsum, set0);
         }
     }
     SOT_HIP(hipGetLastError());
@@ -499,6 +508,8 @@ int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const
         return SOT_EINVAL;
     }
     SOT_HIP(hipSetDevice(c->device));
+    const uint32_t tr0 = 8 * c->ggm_set0, tr1 = 8 * (c->ggm_set0 + c->ggm_nsets);
+    const dim3 gt((tr1 - tr0 + 127) / 128), bt(128);
     // root PRG keys: seed ^ t (pprf.rs:115, Block::from(usize) is the low 64 bits)
     uint64_t Teff = T < c->nsets ? T : c->nsets;
     std::vector<aes_rk> rks(Teff);
@@ -519,23 +530,26 @@ int ggm_sender_expand(sot_ctx *c, const void *base_ots, const void *delta, const
     SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 32, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
     blk_t *V = c->role[SOT_ROLE_SENDER].V;
-    SOT_LAUNCH(c, KID_ROOTS, k_roots, dim3((cf.parts + 127) / 128), dim3(128), c->d_rks, (uint32_t)T,
-                       (uint32_t)cf.parts, c->lvl_a);
+    SOT_LAUNCH(c, KID_ROOTS, k_roots, gt, bt, c->d_rks, (uint32_t)T, tr0, tr1, c->lvl_a);
     SOT_TRY(launch_levels(c, false, V));
     blk_t d;
     memcpy(&d, delta, 16);
-    SOT_LAUNCH(c, KID_SENDER_TG, k_sender_treegrp, dim3((cf.parts + 127) / 128), dim3(128), c->sums, c->d_base, d,
-                       (uint32_t)cf.parts, (uint32_t)cf.depth, c->d_tg_sums, c->d_tg_last);
+    SOT_LAUNCH(c, KID_SENDER_TG, k_sender_treegrp, gt, bt, c->sums, c->d_base, d, (uint32_t)cf.parts, (uint32_t)cf.depth,
+               c->d_tg_sums, c->d_tg_last, tr0, tr1);
     SOT_HIP(hipGetLastError());
+    // the TreeGrps of this context's tree sets (a contiguous range of groups in both flat arrays); a sharded context
+    // leaves the other groups' entries of the caller's arrays untouched
+    const uint64_t sb1 = 2 * (cf.depth - 1) * 8 * 16, lb1 = 8 * 4 * 16;  // bytes per group
     if (tg_sums_out)
-        SOT_HIP(hipMemcpyAsync(tg_sums_out, c->d_tg_sums, sot_treegrp_sums_blocks(&cf) * 16, hipMemcpyDeviceToHost,
-                               c->stream));
+        SOT_HIP(hipMemcpyAsync((char *)tg_sums_out + c->ggm_set0 * sb1, (const char *)c->d_tg_sums + c->ggm_set0 * sb1,
+                               c->ggm_nsets * sb1, hipMemcpyDeviceToHost, c->stream));
     if (tg_last_out)
-        SOT_HIP(hipMemcpyAsync(tg_last_out, c->d_tg_last, sot_treegrp_last_blocks(&cf) * 16, hipMemcpyDeviceToHost,
-                               c->stream));
+        SOT_HIP(hipMemcpyAsync((char *)tg_last_out + c->ggm_set0 * lb1, (const char *)c->d_tg_last + c->ggm_set0 * lb1,
+                               c->ggm_nsets * lb1, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[SOT_ROLE_SENDER].expanded = true;
     c->role[SOT_ROLE_SENDER].encoded = false;
+    c->sh.slots_ready = c->sh.enc_slots_ready = false;
     c->mt_valid = false;
     return SOT_OK;
 }
@@ -549,22 +563,24 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
             sot_set_error("choices must be 0/1 bytes");
             return SOT_EINVAL;
         }
+    const uint32_t tr0 = 8 * c->ggm_set0, tr1 = 8 * (c->ggm_set0 + c->ggm_nsets);
+    const dim3 gt((tr1 - tr0 + 127) / 128), bt(128);
     SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 16, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemcpyAsync(c->d_choices, choices, cf.base_ot_count, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemcpyAsync(c->d_tg_sums, tg_sums, sot_treegrp_sums_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemcpyAsync(c->d_tg_last, tg_last, sot_treegrp_last_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
     SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
     blk_t *V = c->role[SOT_ROLE_RECEIVER].V;
-    dim3 gt((cf.parts + 127) / 128), bt(128);
     SOT_LAUNCH(c, KID_RECV_INIT, k_recv_init, gt, bt, c->d_base, c->d_choices, c->d_tg_sums, (uint32_t)cf.parts,
-                       (uint32_t)cf.depth, c->lvl_b);
+                       (uint32_t)cf.depth, c->lvl_b, tr0, tr1);
     SOT_TRY(launch_levels(c, true, V));
     SOT_LAUNCH(c, KID_RECV_LAST, k_recv_last, gt, bt, c->d_base, c->d_choices, c->d_tg_last,
-                       c->sums + (cf.depth - 1) * c->nsets * 16, (uint32_t)cf.parts, (uint32_t)cf.depth, cf.cols, V);
+                       c->sums + (cf.depth - 1) * c->nsets * 16, (uint32_t)cf.parts, (uint32_t)cf.depth, cf.cols, V, tr0, tr1);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[SOT_ROLE_RECEIVER].expanded = true;
     c->role[SOT_ROLE_RECEIVER].encoded = false;
+    c->sh.slots_ready = c->sh.enc_slots_ready = false;
     c->mt_valid = false;
     return SOT_OK;
 }
@@ -618,13 +634,13 @@ int hash_sender(sot_ctx *c, const void *delta, void *msgs_out) {
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(c->device));
-    SOT_TRY(ensure_tmp(c, cf.n * 32));
+    SOT_TRY(ensure_tmp(c, c->n_out * 32));
     blk_t d;
     memcpy(&d, delta, 16);
-    SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
-                       c->role[SOT_ROLE_SENDER].enc, d, cf.n, (blk_t *)c->d_tmp);
+    SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
+                       c->role[SOT_ROLE_SENDER].enc, d, c->n_out, (blk_t *)c->d_tmp);
     SOT_HIP(hipGetLastError());
-    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 32, hipMemcpyDeviceToHost, c->stream));
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, c->n_out * 32, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
@@ -635,13 +651,17 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
         sot_set_error("receiver_hash before qc_encode");
         return SOT_ESTATE;
     }
+    if (c->recv_unpacked) {  // Receiver::hash reads the choice from bit 0 of A (silent_ot/mod.rs:470-477)
+        sot_set_error("receiver_hash needs ChoiceBitPacking::True; the last encode was unpacked");
+        return SOT_ESTATE;
+    }
     SOT_HIP(hipSetDevice(c->device));
-    SOT_TRY(ensure_tmp(c, cf.n * 32));
-    uint64_t nw = (cf.n + 63) / 64;
-    SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
-                       c->role[SOT_ROLE_RECEIVER].enc, cf.n, (blk_t *)c->d_tmp, c->d_chw);
+    SOT_TRY(ensure_tmp(c, c->n_out * 32));
+    uint64_t nw = (c->n_out + 63) / 64;
+    SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
+                       c->role[SOT_ROLE_RECEIVER].enc, c->n_out, (blk_t *)c->d_tmp, c->d_chw);
     SOT_HIP(hipGetLastError());
-    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, cf.n * 16, hipMemcpyDeviceToHost, c->stream));
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
     if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_chw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
@@ -653,15 +673,19 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
         sot_set_error("mt_bits needs both the sender and the receiver instance encoded");
         return SOT_ESTATE;
     }
+    if (c->recv_unpacked) {
+        sot_set_error("mt_bits needs ChoiceBitPacking::True; the receiver's last encode was unpacked");
+        return SOT_ESTATE;
+    }
     SOT_HIP(hipSetDevice(c->device));
-    uint64_t nw = (cf.n + 63) / 64;
+    uint64_t nw = (c->n_out + 63) / 64;
     blk_t d;
     memcpy(&d, delta, 16);
-    SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(cf.n, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[0].enc,
-                       c->role[1].enc, d, cf.n, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
+    SOT_LAUNCH(c, KID_MT_BITS, k_mt_bits, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[0].enc,
+                       c->role[1].enc, d, c->n_out, c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw);
     SOT_HIP(hipGetLastError());
     c->mt_valid = true;
-    c->mt_rem = cf.n;
+    c->mt_rem = c->n_out;
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (b) SOT_HIP(hipMemcpyAsync(b, c->d_mt + nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (cc) SOT_HIP(hipMemcpyAsync(cc, c->d_mt + 2 * nw, nw * 8, hipMemcpyDeviceToHost, c->stream));

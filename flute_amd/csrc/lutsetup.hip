@@ -217,7 +217,7 @@ extern "C" int sot_and_circ_layer_msg(sot_and_circ *q, uint32_t layer, uint8_t *
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(c->device));
-    const uint64_t nw = (c->conf.n + 63) / 64;
+    const uint64_t nw = (c->n_out + 63) / 64;
     const uint64_t mt0 = c->mt_rem - cnt;  // split_off_last(cnt), executor.rs:139
     SOT_LAUNCH(c, KID_AND_MSG, k_and_msg, dim3(lgrid(cnt)), dim3(256), q->vals, q->xpos, q->ypos, q->goff[layer], cnt,
                c->d_mt, c->d_mt + nw, mt0, q->d_own, q->e_own);
@@ -237,7 +237,7 @@ extern "C" int sot_and_circ_layer_msg(sot_and_circ *q, uint32_t layer, uint8_t *
 
 static int and_eval_launch(sot_and_circ *q, uint32_t layer, uint32_t party, const uint64_t *pd, const uint64_t *pe) {
     sot_ctx *c = q->ctx;
-    const uint64_t nw = (c->conf.n + 63) / 64;
+    const uint64_t nw = (c->n_out + 63) / 64;
     SOT_LAUNCH(c, KID_AND_EVAL, k_and_eval, dim3(lgrid(q->count[layer])), dim3(256), q->d_own, q->e_own, pd, pe, c->d_mt,
                c->d_mt + nw, c->d_mt + 2 * nw, q->mt0[layer], q->count[layer], party, q->vals + q->base[layer] / 64);
     SOT_HIP(hipGetLastError());

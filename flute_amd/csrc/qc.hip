@@ -84,11 +84,73 @@ __global__ void k_set_points(uint32_t *__restrict__ sb, const uint64_t *__restri
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npts && pts[i] < nV) atomicOr(sb + (pts[i] >> 5), 1u << (pts[i] & 31));
 }
-// V[idx], with bit 0 := sb[idx] when sb != nullptr (receiver with packed choice bits)
-__device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t idx, const uint32_t *__restrict__ sb) {
+// V[idx], with bit `sbpos` := sb[idx] when sb != nullptr (receiver with packed choice bits: sbpos = 0, the receiver's
+// bit row 0; in the slot Blocks of a sharded context the receiver's row 0 is slot 128 / world of rank 0, shard.hip)
+__device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t idx, const uint32_t *__restrict__ sb,
+                                         uint32_t sbpos) {
     blk_t v = V[idx];
-    if (sb) v.x = (v.x & ~1u) | ((sb[idx >> 5] >> (idx & 31)) & 1u);
+    if (sb) {
+        const uint32_t sh = sbpos & 31u, m = ~(1u << sh), b = ((sb[idx >> 5] >> (idx & 31)) & 1u) << sh;
+        switch (sbpos >> 5) {  // kernel-uniform
+            case 0: v.x = (v.x & m) | b; break;
+            case 1: v.y = (v.y & m) | b; break;
+            case 2: v.z = (v.z & m) | b; break;
+            default: v.w = (v.w & m) | b; break;
+        }
+    }
     return v;
+}
+
+// receiver with UNPACKED choice bits (ChoiceBitPacking::False, quasi_cyclic_encode.rs:65-68,104-117): all 128 rows of A
+// come from rT and the choice vector is a 129th product, C = reduce(sb) (c128, :105-106), one byte per OT (:108-115).
+// sb has only `parts` set bits, so that product is a sum of `parts` cyclic shifts of a' = a mod (x^P - 1) -- no
+// transform:  C[k] = [k in S0'] ^ XOR_{s in S1} a'[(k - s) mod P]
+//   S0' = {S mod P : S < nb128} (the b0 half of the row, folded), S1 = {(S - nb128) mod P : nb128 <= S < 2 nb128}
+// (row halves split at Block n_blocks, quasi_cyclic_encode.rs:267; points in the last cols - 2 n_blocks Blocks are
+// outside both halves). pts[i] = pos | kind << 63 (kind 1: an S0' position), ~0 = dropped. One thread per 32 OTs.
+#define SC_DROPPED (~0ull)
+__device__ __forceinline__ uint32_t cyc32(const uint32_t *__restrict__ a, uint64_t P, uint64_t start) {
+    // bits a'[(start + i) mod P], i < 32; a' has zero bits from P on and two padding words
+    const uint64_t w0 = start >> 5;
+    const uint32_t sh = (uint32_t)(start & 31);
+    uint32_t v = a[w0] >> sh;
+    if (sh) v |= a[w0 + 1] << (32 - sh);
+    const uint64_t rem = P - start;  // >= 1
+    if (rem < 32) v |= a[0] << rem;  // P > 32: at most one wrap
+    return v;
+}
+__global__ void __launch_bounds__(256)
+    k_sparse_choice(const uint32_t *__restrict__ a2, uint64_t P, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t n,
+                    uint8_t *__restrict__ C) {
+    __shared__ uint64_t sp[256];
+    for (uint32_t i = threadIdx.x; i < npts; i += blockDim.x) sp[i] = pts[i];
+    __syncthreads();
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k0 = 32 * w;
+    if (k0 >= n) return;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < npts; i++) {
+        const uint64_t e = sp[i];
+        if (e == SC_DROPPED) continue;
+        const uint64_t pos = e & ~(1ull << 63);
+        if (e >> 63) {
+            if ((pos >> 5) == w) v ^= 1u << (pos & 31);
+        } else {
+            v ^= cyc32(a2, P, k0 >= pos ? k0 - pos : k0 + P - pos);
+        }
+    }
+    if (k0 + 32 <= n) {
+        uint32_t o[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            o[q] = ((v >> (4 * q)) & 1u) | (((v >> (4 * q + 1)) & 1u) << 8) | (((v >> (4 * q + 2)) & 1u) << 16) |
+                   (((v >> (4 * q + 3)) & 1u) << 24);
+        uint4 *d = (uint4 *)(C + k0);
+        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (uint64_t k = k0; k < n; k++) C[k] = (uint8_t)((v >> (k - k0)) & 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -100,17 +162,17 @@ __device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t i
 #define LD_W 32
 #define LD_T 128
 __global__ void __launch_bounds__(LD_T)
-    k_qc_load(const blk_t *__restrict__ V, const uint32_t *__restrict__ sb, uint64_t v1_len, uint64_t P, uint64_t lo_bits,
-              uint64_t nw_half, uint32_t *__restrict__ Z) {
+    k_qc_load(const blk_t *__restrict__ V, const uint32_t *__restrict__ sb, uint32_t sbpos, uint64_t v1_len, uint64_t P,
+              uint64_t lo_bits, uint64_t nw_half, uint32_t *__restrict__ Z) {
     __shared__ uint32_t tio[LD_W * 132];  // in: [w][p][q] words (stride 132); out: [w][row] (stride 129)
     const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
     for (uint32_t i = threadIdx.x; i < LD_W * 32; i += LD_T) {
         const uint64_t c = w0 * 32 + i;
         blk_t v = make_uint4(0, 0, 0, 0);
         if (c < lo_bits) {
-            v = ld_leaf(V, v1_len + c, sb);  // V1 = V + nb128 and v1_len == nb128
+            v = ld_leaf(V, v1_len + c, sb, sbpos);  // V1 = V + nb128 and v1_len == nb128
             if (c + P < v1_len) {
-                blk_t u = ld_leaf(V, v1_len + c + P, sb);
+                blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos);
                 v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
             }
         }
@@ -1869,10 +1931,11 @@ __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64
 //   B[k] = V0[k] ^ V0[k+P] ^ T[k] ^ T[k+P] ^ sum_{i: a_hi[i]} V1'[(k - S - i) mod P]
 //                                         ^ sum_{j < tail} a_lo[(k - S - j) mod P] V1'[S + j]
 // V0 = V[0 .. nb128), V1' = (V1 mod x^P - 1). a2 = a' repeated twice as a bit vector.
-__device__ __forceinline__ blk_t ld_v1p(const blk_t *V, const uint32_t *sb, uint64_t v1_len, uint64_t P, uint64_t c) {
-    blk_t v = ld_leaf(V, v1_len + c, sb);  // V1 = V + nb128, v1_len == nb128
+__device__ __forceinline__ blk_t ld_v1p(const blk_t *V, const uint32_t *sb, uint32_t sbpos, uint64_t v1_len, uint64_t P,
+                                        uint64_t c) {
+    blk_t v = ld_leaf(V, v1_len + c, sb, sbpos);  // V1 = V + nb128, v1_len == nb128
     if (c + P < v1_len) {
-        blk_t u = ld_leaf(V, v1_len + c + P, sb);
+        blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos);
         v.x ^= u.x;
         v.y ^= u.y;
         v.z ^= u.z;
@@ -1896,7 +1959,7 @@ static inline size_t fn_dyn_lds(uint32_t tail) {
 }
 __global__ void __launch_bounds__(256)
     k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, const uint32_t *__restrict__ sb,
-                uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
+                uint32_t sbpos, uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
                 const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out) {
     __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
     // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
@@ -1927,10 +1990,10 @@ __global__ void __launch_bounds__(256)
         for (uint32_t x = threadIdx.x; x < FN_K + tail - 1; x += 256) {
             uint64_t cc = c0 + x;
             if (cc >= P) cc -= P;
-            win[x] = ld_v1p(V, sb, nb128, P, cc);
+            win[x] = ld_v1p(V, sb, sbpos, nb128, P, cc);
             abit[x] = cc < S ? (uint8_t)(0u - ((a2[cc >> 5] >> (cc & 31)) & 1u)) : (uint8_t)0;
         }
-        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V, sb, nb128, P, S + j);
+        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V, sb, sbpos, nb128, P, S + j);
     }
     __syncthreads();
     {
@@ -1955,10 +2018,10 @@ __global__ void __launch_bounds__(256)
         if (k >= n) break;
         const uint32_t *sp = tio + (kl >> 5) * 132 + (kl & 31) * 4;
         blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        blk_t u = ld_leaf(V, k, sb);
+        blk_t u = ld_leaf(V, k, sb, sbpos);
         r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         if (k + P < nb128) {
-            u = ld_leaf(V, k + P, sb);
+            u = ld_leaf(V, k + P, sb, sbpos);
             r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         }
         if (tail && !(QC_EXP & 4)) {
@@ -2552,23 +2615,28 @@ void qc_free(sot_ctx *c) {
         if (p) hipFree(p);
 }
 
-int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
+// noise indicator bit vector sb (one bit per leaf Block) from the receiver's interleaved points
+static int qc_set_points(sot_ctx *c, const uint64_t *points, uint64_t npoints) {
+    const uint64_t nV = c->conf.cols * 128;
+    SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemsetAsync(c->sbv, 0, (nV / 32 + 2) * 4, c->stream));
+    SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), c->sbv, c->d_points,
+               (uint32_t)npoints, nV);
+    return SOT_OK;
+}
+
+// leaves V (Blocks, or slot Blocks of a sharded context) -> encoded Blocks out[0 .. n): load, forward transform,
+// pointwise multiply, inverse transform, finish. Asynchronous on the context's stream.
+static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32_t sbpos, blk_t *out) {
     const sot_conf &cf = c->conf;
     const qc_geom &g = c->g;
-    SOT_HIP(hipSetDevice(c->device));
-    blk_t *V = c->role[role].V;
     const uint64_t nb128 = cf.n_blocks * 128;
-    const uint64_t nV = cf.cols * 128;
     const fft_plan &plan = *(const fft_plan *)c->qc_plan;
-    const uint32_t *sb = nullptr;
-    if (role == SOT_ROLE_RECEIVER) {
-        SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
-        SOT_HIP(hipMemsetAsync(c->sbv, 0, (nV / 32 + 2) * 4, c->stream));
-        SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), c->sbv, c->d_points,
-                   (uint32_t)npoints, nV);
-        sb = c->sbv;
+    if (g.tail > FN_TAILMAX) {
+        sot_set_error("internal: tail exceeds FN_TAILMAX");
+        return SOT_EINVAL;
     }
-    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, nb128, cf.P, g.lo_bits,
+    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
                g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
@@ -2578,17 +2646,64 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints) {
     if (c->prof) prof_end(c, KID_FFT_LOW_MUL);
     fft_inverse_upper(c, zb[cur], plan);
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
-    if (g.tail > FN_TAILMAX) {
-        sot_set_error("internal: tail exceeds FN_TAILMAX");
-        return SOT_EINVAL;
-    }
     if (c->prof) prof_begin(c, KID_QC_FINAL);
     hipLaunchKernelGGL(k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                       g.nw, V, sb, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, c->role[role].enc);
+                       g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out);
     if (c->prof) prof_end(c, KID_QC_FINAL);
     SOT_HIP(hipGetLastError());
+    return SOT_OK;
+}
+
+int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, int packed, uint8_t *C_out) {
+    const sot_conf &cf = c->conf;
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t nb128 = cf.n_blocks * 128;
+    const uint32_t *sb = nullptr;
+    if (role == SOT_ROLE_RECEIVER && !packed) {
+        // the choice vector: sparse sum of shifts of a' (k_sparse_choice); A itself is the plain encode of all 128 rows
+        if (npoints > 256 || cf.n > c->tmp_bytes) {
+            sot_set_error("internal: unpacked choice vector does not fit (points %llu)", (unsigned long long)npoints);
+            return SOT_EINVAL;
+        }
+        std::vector<uint64_t> e(npoints);
+        for (uint64_t i = 0; i < npoints; i++) {
+            const uint64_t S = points[i];
+            if (S < nb128)
+                e[i] = (S % cf.P) | (1ull << 63);
+            else if (S < 2 * nb128)
+                e[i] = (S - nb128) % cf.P;
+            else
+                e[i] = SC_DROPPED;
+        }
+        SOT_HIP(hipMemcpyAsync(c->d_points, e.data(), npoints * 8, hipMemcpyHostToDevice, c->stream));
+        SOT_LAUNCH(c, KID_CLEAR_LSB, k_sparse_choice, dim3(gridn((cf.n + 31) / 32, 256)), dim3(256), c->a2, cf.P, c->d_points,
+                   (uint32_t)npoints, cf.n, (uint8_t *)c->d_tmp);
+        SOT_HIP(hipGetLastError());
+        SOT_HIP(hipMemcpyAsync(C_out, c->d_tmp, cf.n, hipMemcpyDeviceToHost, c->stream));
+        SOT_HIP(hipStreamSynchronize(c->stream));  // e goes out of scope; C_out is complete
+    } else if (role == SOT_ROLE_RECEIVER) {
+        SOT_TRY(qc_set_points(c, points, npoints));
+        sb = c->sbv;
+    }
+    SOT_TRY(qc_encode_core(c, c->role[role].V, sb, 0, c->role[role].enc));
     SOT_HIP(hipStreamSynchronize(c->stream));
     c->role[role].encoded = true;
+    if (role == SOT_ROLE_RECEIVER) c->recv_unpacked = !packed;
+    return SOT_OK;
+}
+
+// Sharded context: ONE pass over the slot Blocks W encodes this rank's bit rows of the sender AND the receiver matrix
+// (the 128 rows of a wave's two halves are 2 x 128 / world sender + receiver rows; both multiply the same public a, so
+// every mask is shared). The receiver's bit row 0 -- the row dual_encode2 replaces by sb -- is slot 128 / world of rank 0.
+int qc_encode_slots(sot_ctx *c, const uint64_t *points, uint64_t npoints, blk_t *out) {
+    SOT_HIP(hipSetDevice(c->device));
+    const uint32_t *sb = nullptr;
+    if (c->sh.rank == 0) {
+        SOT_TRY(qc_set_points(c, points, npoints));
+        sb = c->sbv;
+    }
+    SOT_TRY(qc_encode_core(c, c->sh.W, sb, c->sh.rpr, out));
+    SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
 

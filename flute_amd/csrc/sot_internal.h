@@ -71,6 +71,8 @@ enum sot_kid {
     KID_QC_FINAL,
     KID_AND_MSG,
     KID_AND_EVAL,
+    KID_SHARD_PACK,
+    KID_SHARD_UNPACK,
     KID_COUNT
 };
 extern const char *const SOT_KID_NAMES[KID_COUNT];
@@ -97,6 +99,25 @@ enum sot_opt {
     SOT_OPT_NO_GGM_TOP = 16  // SOT_NO_GGM_TOP: every GGM level as its own launch
 };
 
+// One expansion sharded over `world` GPUs (shard.hip). Rank r owns
+//   - the tree sets [set0, set0 + nl) of the GGM stage (unless the GGM stage is replicated),
+//   - the bit rows [r * rpr, (r + 1) * rpr), rpr = 128 / world, of BOTH roles' leaf matrices in the QC stage, as "slots"
+//     of one combined Block per leaf: bits [0, rpr) = sender rows, bits [rpr, 2 rpr) = receiver rows, the rest zero,
+//   - the outputs k in [k0, k0 + n_local) of the hash / MT-bit stage.
+struct shard_state {
+    uint32_t rank = 0, world = 1;
+    uint32_t rpr = 128;          // bit rows per rank and role
+    bool ggm_replicated = false;  // every rank expands all trees (no exchange #1) instead of its own tree sets
+    uint32_t nl_max = 0;         // tree sets per rank, maximum over ranks
+    uint64_t nk = 0;             // leaf tiles per tree set = ceil(cols / nsets)
+    uint64_t chunk = 0;          // outputs per rank (a multiple of 64: MT words never straddle ranks)
+    uint64_t k0 = 0, n_local = 0;
+    uint64_t x1_bytes = 0;       // exchange #1: bytes this rank sends to EACH peer (leaf slices, both roles)
+    uint64_t x2_bytes = 0;       // exchange #2: bytes this rank sends to EACH peer (encoded slices of chunk outputs)
+    blk_t *W = nullptr;          // slot Blocks of every leaf, cols * 128
+    bool slots_ready = false, enc_slots_ready = false;
+};
+
 struct sot_ctx {
     // every sot_* entry point that takes the context holds this lock for the whole call: sender and receiver share the
     // GGM scratch, the Z buffers and one stream, and the reference drives both directions from two threads
@@ -109,6 +130,9 @@ struct sot_ctx {
     sot_conf conf;
     qc_geom g;
     uint64_t nsets = 0;  // parts / 8
+    uint32_t ggm_set0 = 0, ggm_nsets = 0;  // the tree sets this context expands (all of them unless sharded)
+    uint64_t n_out = 0;  // outputs held in role[].enc: conf.n, or this rank's n_local when sharded
+    shard_state sh;
     uint64_t dev_bytes = 0;
     role_state role[2];
     // GGM scratch
@@ -135,6 +159,7 @@ struct sot_ctx {
     // MT bits
     uint64_t *d_mt = nullptr;  // a | b | c words
     uint64_t *d_chw = nullptr; // receiver choice words of sot_receiver_hash (kept apart from the MT store)
+    bool recv_unpacked = false;  // the receiver's last encode kept bit row 0 (ChoiceBitPacking::False): A carries no choice bit
     bool mt_valid = false;     // set by hash_mt_bits, cleared by the next expand
     uint64_t mt_rem = 0;       // triples not yet consumed by sot_and_circ_layer_msg (taken from the END of the store)
     void *d_tmp = nullptr;     // download staging
@@ -174,7 +199,19 @@ int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk
 // ---- qc.hip
 int qc_init(sot_ctx *c);
 void qc_free(sot_ctx *c);
-int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints);
+int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, int packed = 1, uint8_t *C_out = nullptr);
+// both roles of a sharded context at once: slot Blocks W -> slot-form outputs (the send buffer of exchange #2)
+int qc_encode_slots(sot_ctx *c, const uint64_t *points, uint64_t npoints, blk_t *out);
 int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out);
 
 int dev_alloc(sot_ctx *c, void **p, uint64_t bytes);
+
+// ---- shard.hip
+int shard_init(sot_ctx *c, uint32_t rank, uint32_t world, int ggm_replicated);
+void shard_free(sot_ctx *c);
+// set range of rank r when `nsets` tree sets are dealt to `world` ranks in contiguous runs
+static inline void shard_sets_of(uint32_t nsets, uint32_t world, uint32_t r, uint32_t *set0, uint32_t *nl) {
+    const uint32_t base = nsets / world, rem = nsets % world;
+    *set0 = r * base + (r < rem ? r : rem);
+    *nl = base + (r < rem ? 1u : 0u);
+}

@@ -1,8 +1,11 @@
-"""Multi-GPU plumbing for the weak-scaling shard: one process per GPU, independent silent-OT instances per rank.
-The expansion itself needs no collective; the one exchange step is the all-gather that reassembles the party's MT
-store (the three bit vectors a, b, c of every rank's instance, 6 MiB per rank at n = 2^24) on every GPU --
-torch.distributed all_gather_into_tensor = RCCL over xGMI on GPUs, gloo on CPU. The barrier and the max-over-ranks of
-the timing go through the same process group. Used by bench.py; covered on CPU by tests/test_dist_gloo.py."""
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; gloo on CPU).
+
+Strong scaling (default of bench.py --gpus N): ONE expansion sharded over the ranks -- tree sets in the GGM stage, bit
+rows of both roles in the QC stage, output ranges in the hash stage (csrc/shard.hip). Two all-to-alls move the leaf
+slices and the encoded slices between the stages (ShardedPipeline), an all-gather reassembles the MT words
+(gather_sharded_mt). Weak scaling (--mode weak): independent instances per rank, all-gather of the MT store only.
+The barrier and the max-over-ranks of the timing go through the same process group. Covered on CPU by
+tests/test_dist_gloo.py, on one GPU by tests/test_gpu_shard.py (all ranks in one process, copies instead of RCCL)."""
 import os
 
 
@@ -68,3 +71,104 @@ def gather_mt_store(engine, world, buf=None):
         buf = torch.empty(nw3, dtype=torch.int64, device=torch.device("cuda", engine.device))
     engine.mt_bits_to_device(buf.data_ptr(), nw3 * 8)
     return all_gather_words(buf, world), buf
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strong scaling: one expansion over all ranks
+def all_to_all_bytes(send, world, out=None):
+    """send: 1-D uint8 tensor of world equal messages, message q for rank q. Returns the tensor whose message r came from
+    rank r (torch.distributed.all_to_all_single). RCCL takes device tensors directly; gloo (rehearsals of GPU ranks on a
+    one-GPU box, CPU tests) moves host memory, so device tensors are staged through the host for it."""
+    import torch
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty_like(send)
+    if world <= 1:
+        out.copy_(send)
+        return out
+    if send.is_cuda and dist.get_backend() == "gloo":
+        h_in, h_out = send.cpu(), torch.empty(send.numel(), dtype=send.dtype)
+        dist.all_to_all_single(h_out, h_in)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, send)
+    return out
+
+
+def gather_sharded_words(local, world):
+    """local: [3, chunk / 64] int64 words (a | b | c of this rank's outputs). Returns [3, world * chunk / 64] on every
+    rank: vector v of the whole expansion = the ranks' words of v in rank order (chunk is a multiple of 64)."""
+    import torch
+    if world <= 1:
+        return local
+    import torch.distributed as dist
+    flat = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        h = torch.empty(flat.numel(), dtype=local.dtype)
+        dist.all_gather_into_tensor(h, local.contiguous().cpu())
+        flat.copy_(h)
+    else:
+        dist.all_gather_into_tensor(flat, local.contiguous())
+    return flat.reshape(world, 3, -1).permute(1, 0, 2).reshape(3, -1)
+
+
+class ShardedPipeline:
+    """One rank's side of a sharded precompute_mts step (gmw/src/mul_triple/silent_ot.rs:79-114 for ONE expansion over
+    `world` GPUs). `exchange(send, recv)` is the all-to-all: all_to_all_bytes over torch.distributed by default; the
+    single-process tests pass a function that copies between the ranks' buffers instead."""
+
+    def __init__(self, engine, exchange=None, torch_device=None):
+        import torch
+        self.eng, self.world = engine, engine.world
+        dev = torch_device if torch_device is not None else torch.device("cuda", engine.device)
+        self.send1 = self.recv1 = None
+        if not engine.ggm_replicated:
+            self.send1 = torch.empty(engine.world * engine.x1_bytes, dtype=torch.uint8, device=dev)
+            self.recv1 = torch.empty_like(self.send1)
+        self.send2 = torch.empty(engine.world * engine.x2_bytes, dtype=torch.uint8, device=dev)
+        self.recv2 = torch.empty_like(self.send2)
+        nwl = engine.chunk // 64
+        self.mt = torch.zeros(3, nwl, dtype=torch.int64, device=dev)
+        self.exchange = exchange or (lambda s, r: all_to_all_bytes(s, self.world, r))
+
+    def expand(self, sender_base, delta, seed, threads, recv_base, recv_choices, tg_sums, tg_last):
+        """both directions' GGM stage on this rank's tree sets; returns this rank's TreeGrps (flat arrays, own groups)"""
+        tg = self.eng.sender_expand(sender_base, delta, seed, threads)
+        self.eng.receiver_expand(recv_base, recv_choices, tg_sums, tg_last)
+        return tg
+
+    def exchange_leaves(self):
+        if self.eng.ggm_replicated:
+            self.eng.local_leaves()
+            return
+        self.eng.pack_leaves(self.send1.data_ptr())
+        self.exchange(self.send1, self.recv1)
+        self.sync_exchange()
+        self.eng.unpack_leaves(self.recv1.data_ptr())
+
+    def encode(self, points):
+        self.eng.shard_qc_encode(points, self.send2.data_ptr())
+        self.exchange(self.send2, self.recv2)
+        self.sync_exchange()
+        self.eng.unpack_encoded(self.recv2.data_ptr())
+
+    def sync_exchange(self):
+        """the collective ran on torch's stream, the engine's kernels run on the context's: order them"""
+        import torch
+        if self.recv2.is_cuda:
+            torch.cuda.current_stream(self.recv2.device).synchronize()
+
+    def mt_bits(self, delta, gather=True):
+        """fused hashes + MT bits on this rank's outputs; with `gather`, the whole expansion's a | b | c words
+        ([3, world * chunk / 64] int64, the first ceil(n / 64) of each row are the MulTriples vectors) on every rank"""
+        self.eng.mt_bits(delta, download=False)
+        nwl = (self.eng.n_out + 63) // 64
+        if nwl:
+            import torch
+            tmp = torch.empty(3 * nwl, dtype=torch.int64, device=self.mt.device)
+            self.eng.mt_bits_to_device(tmp.data_ptr(), 3 * nwl * 8)
+            self.mt.zero_()
+            self.mt[:, :nwl] = tmp.reshape(3, nwl)
+        else:
+            self.mt.zero_()
+        return gather_sharded_words(self.mt, self.world) if gather else self.mt

@@ -22,17 +22,24 @@ class Conf(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class ShardInfo(C.Structure):
+    """sot_shard_info (include/flute_sot.h)"""
+    _fields_ = [(k, C.c_uint32) for k in ("rank", "world", "set0", "nsets_local", "ggm_replicated", "rows_per_rank")] + \
+               [(k, C.c_uint64) for k in ("k0", "n_local", "chunk", "x1_bytes_per_peer", "x2_bytes_per_peer")]
+
+
 EXPORTS = [
     "sot_last_error", "sot_device_count", "sot_configure", "sot_ctx_create", "sot_ctx_destroy", "sot_ctx_conf",
     "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
     "sot_sender_expand", "sot_receiver_expand", "sot_receiver_points", "sot_download_rT", "sot_qc_encode",
-    "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_random_silent_send",
+    "sot_qc_encode2", "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_random_silent_send",
     "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
     "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
     "sot_and_circ_set_inputs", "sot_and_circ_layer_msg", "sot_and_circ_layer_eval", "sot_and_circ_layer_eval_peer",
     "sot_and_circ_values", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
-    "sot_alsz_noalloc_max_count",
+    "sot_alsz_noalloc_max_count", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves",
+    "sot_shard_unpack_leaves", "sot_shard_local_leaves", "sot_shard_qc_encode", "sot_shard_unpack_encoded",
 ]
 
 
@@ -74,6 +81,7 @@ def load_library():
     L.sot_receiver_points.argtypes = [C.POINTER(Conf), P, P]
     L.sot_download_rT.argtypes = [P, i32, P]
     L.sot_qc_encode.argtypes = [P, i32, P, u64]
+    L.sot_qc_encode2.argtypes = [P, P, u64, i32, P]
     L.sot_download_encoded.argtypes = [P, i32, P]
     L.sot_sender_hash.argtypes = [P, P, P]
     L.sot_receiver_hash.argtypes = [P, P, P]
@@ -108,6 +116,13 @@ def load_library():
     L.sot_alsz_send.argtypes = [i32, P, P, P, u64, P]
     L.sot_alsz_receive_noalloc.argtypes = [i32, P, P, u64, P, P]
     L.sot_alsz_noalloc_max_count.restype = u64
+    L.sot_ctx_create_sharded.argtypes = [u64, u64, i32, C.c_uint32, C.c_uint32, i32, C.POINTER(P)]
+    L.sot_shard_info_get.argtypes = [P, C.POINTER(ShardInfo)]
+    L.sot_shard_pack_leaves.argtypes = [P, P]
+    L.sot_shard_unpack_leaves.argtypes = [P, P]
+    L.sot_shard_local_leaves.argtypes = [P]
+    L.sot_shard_qc_encode.argtypes = [P, P, u64, P]
+    L.sot_shard_unpack_encoded.argtypes = [P, P]
     L.sot_mt_remaining.restype = u64
     for name in EXPORTS:
         fn = getattr(L, name)

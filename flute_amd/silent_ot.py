@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import Conf, check, load_library
+from .lib import Conf, ShardInfo, check, load_library
 
 SECURITY_PARAM = 128  # silent_ot/mod.rs
 ROLE_SENDER, ROLE_RECEIVER = 0, 1
@@ -101,10 +101,14 @@ class Engine:
         h = C.c_void_p()
         check(self.lib.sot_ctx_create(num_ots, scaler, device, C.byref(h)))
         self.h = h
+        self._finish_init(device)
+
+    def _finish_init(self, device):
         c = Conf()
         check(self.lib.sot_ctx_conf(self.h, C.byref(c)))
         self.conf = QuasiCyclicConf(c)
         self.device = device
+        self.n_out = self.conf.n  # outputs of the hash stage held by this context (a sharded one holds n_local)
         self._circuits = []  # AndCircuit objects evaluated on this context (lut_setup.py)
 
     def close(self):
@@ -203,6 +207,17 @@ class Engine:
         else:
             check(self.lib.sot_qc_encode(self.h, role, None, 0))
 
+    def qc_encode2(self, points, packed=True):
+        """QuasiCyclicEncoder::dual_encode2 with the ChoiceBitPacking as an argument (quasi_cyclic_encode.rs:54-124).
+        Returns None (packed) or the choice vector C as n bytes 0/1 (unpacked)."""
+        pts = np.ascontiguousarray(points, dtype=np.uint64)
+        if packed:
+            check(self.lib.sot_qc_encode2(self.h, _p(pts), pts.size, 1, None))
+            return None
+        Cv = np.zeros(self.conf.n, dtype=np.uint8)
+        check(self.lib.sot_qc_encode2(self.h, _p(pts), pts.size, 0, _p(Cv)))
+        return Cv
+
     def qc_dual_encode_host(self, role, rT, points=None):
         rT = np.ascontiguousarray(rT, dtype=np.uint64)
         if rT.shape != (128, self.conf.cols, 2):
@@ -216,25 +231,25 @@ class Engine:
         return out
 
     def download_encoded(self, role):
-        out = np.zeros((self.conf.n, 2), dtype=np.uint64)
+        out = np.zeros((self.n_out, 2), dtype=np.uint64)
         check(self.lib.sot_download_encoded(self.h, role, _p(out)))
         return out
 
     def sender_hash(self, delta, download=True):
         d = _blk(delta)
-        out = np.zeros((self.conf.n, 2, 2), dtype=np.uint64) if download else None
+        out = np.zeros((self.n_out, 2, 2), dtype=np.uint64) if download else None
         check(self.lib.sot_sender_hash(self.h, _p(d), _p(out) if download else None))
         return out
 
     def receiver_hash(self, download=True):
-        n = self.conf.n
+        n = self.n_out
         out = np.zeros((n, 2), dtype=np.uint64) if download else None
         ch = np.zeros((n + 63) // 64, dtype=np.uint64)
         check(self.lib.sot_receiver_hash(self.h, _p(out) if download else None, _p(ch)))
         return out, ch
 
     def mt_bits(self, delta, download=True):
-        n = self.conf.n
+        n = self.n_out
         d = _blk(delta)
         nw = (n + 63) // 64
         if not download:
@@ -249,11 +264,52 @@ class Engine:
 
     def mt_words(self):
         """3 * ceil(n / 64): length in u64 of the a | b | c buffer of mt_bits_to_device."""
-        return 3 * ((self.conf.n + 63) // 64)
+        return 3 * ((self.n_out + 63) // 64)
 
     def mt_bits_to_device(self, device_ptr, nbytes):
         """a | b | c words of the last mt_bits() into a caller-owned device buffer (a torch tensor's data_ptr())."""
         check(self.lib.sot_mt_bits_to_device(self.h, C.c_void_p(device_ptr), nbytes))
+
+
+class ShardedEngine(Engine):
+    """Rank `rank` of ONE expansion sharded over `world` GPUs (include/flute_sot.h, sot_shard_*):
+    this rank's tree sets in the GGM stage, its 128 / world bit rows of both roles in the QC stage, its n_local outputs
+    in the hash stage. The two all-to-alls between the stages are run by the caller on device buffers
+    (flute_amd.dist.ShardedPipeline over torch.distributed)."""
+
+    def __init__(self, num_ots, rank, world, mult_type=None, device=0, ggm_replicated=False):
+        self.lib = load_library()
+        scaler = (mult_type or MultType()).scaler
+        h = C.c_void_p()
+        check(self.lib.sot_ctx_create_sharded(num_ots, scaler, device, rank, world, 1 if ggm_replicated else 0,
+                                              C.byref(h)))
+        self.h = h
+        self._finish_init(device)
+        info = ShardInfo()
+        check(self.lib.sot_shard_info_get(self.h, C.byref(info)))
+        self.info = info
+        self.rank, self.world = rank, world
+        self.ggm_replicated = bool(info.ggm_replicated)
+        self.n_out = int(info.n_local)
+        self.k0, self.chunk = int(info.k0), int(info.chunk)
+        self.x1_bytes, self.x2_bytes = int(info.x1_bytes_per_peer), int(info.x2_bytes_per_peer)
+        self.groups = range(int(info.set0), int(info.set0) + int(info.nsets_local))  # TreeGrps this rank makes / needs
+
+    def pack_leaves(self, send_ptr):
+        check(self.lib.sot_shard_pack_leaves(self.h, C.c_void_p(send_ptr)))
+
+    def unpack_leaves(self, recv_ptr):
+        check(self.lib.sot_shard_unpack_leaves(self.h, C.c_void_p(recv_ptr)))
+
+    def local_leaves(self):
+        check(self.lib.sot_shard_local_leaves(self.h))
+
+    def shard_qc_encode(self, points, send_ptr):
+        pts = np.ascontiguousarray(points, dtype=np.uint64)
+        check(self.lib.sot_shard_qc_encode(self.h, _p(pts), pts.size, C.c_void_p(send_ptr)))
+
+    def unpack_encoded(self, recv_ptr):
+        check(self.lib.sot_shard_unpack_encoded(self.h, C.c_void_p(recv_ptr)))
 
 
 class Sender:
@@ -305,11 +361,15 @@ class Receiver:
         """mod.rs:353-384"""
         return cls(engine, silent_base_ots, silent_base_choices, num_threads)
 
-    def correlated_silent_receive(self, tree_groups):
-        """mod.rs:410-435 with ChoiceBitPacking::True. Returns A (choice bit packed in bit 0)."""
+    def correlated_silent_receive(self, tree_groups, choice_bit_packing=True):
+        """mod.rs:410-435. ChoiceBitPacking::True: returns A with the choice bit packed in bit 0;
+        ChoiceBitPacking::False: returns (A, C) with C the choice vector, one byte per OT (Option<Vec<u8>>)."""
         self.engine.receiver_expand(self.base_ots, self.choices, *tree_groups)
-        self.engine.qc_encode(ROLE_RECEIVER, self.S)
-        return self.engine.download_encoded(ROLE_RECEIVER)
+        if choice_bit_packing:
+            self.engine.qc_encode(ROLE_RECEIVER, self.S)
+            return self.engine.download_encoded(ROLE_RECEIVER)
+        Cv = self.engine.qc_encode2(self.S, packed=False)
+        return self.engine.download_encoded(ROLE_RECEIVER), Cv
 
     def random_silent_receive(self, tree_groups):
         """mod.rs:391-404. Returns (Vec<Block> [n,2], choices as ceil(n/64) u64 words, Lsb0)."""

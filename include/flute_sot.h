@@ -102,6 +102,13 @@ int sot_download_rT(sot_ctx *ctx, int role, void *rT_out);
  * dual_encode2 with ChoiceBitPacking::True (receiver, :54-124, silent_ot/mod.rs:552-575).
  * For the receiver `points` are the `parts` interleaved noisy positions S. */
 int sot_qc_encode(sot_ctx *ctx, int role, const uint64_t *points, uint64_t npoints);
+/* QuasiCyclicEncoder::dual_encode2(rT, sb, choice_bit_packing) for the receiver with the packing as an argument
+ * (quasi_cyclic_encode.rs:54-124; silent_ot/mod.rs:410-435). packing != 0: ChoiceBitPacking::True, same as
+ * sot_qc_encode(ctx, SOT_ROLE_RECEIVER, ...), C_out is ignored. packing == 0: ChoiceBitPacking::False (what the
+ * reference's correlated_silent_ot test uses, silent_ot/mod.rs:867): all 128 rows of A come from rT and the choice
+ * vector is returned separately, C_out[i] = 0/1 for i < n (the Option<Vec<u8>> of :104-117). After an unpacked encode
+ * sot_receiver_hash / sot_mt_bits return SOT_ESTATE (Receiver::hash takes the choice from bit 0 of A). */
+int sot_qc_encode2(sot_ctx *ctx, const uint64_t *points, uint64_t npoints, int packing, uint8_t *C_out);
 /* correlated_silent_send / correlated_silent_receive outputs: n Blocks (silent_ot/mod.rs:217,410) */
 int sot_download_encoded(sot_ctx *ctx, int role, void *blocks_out);
 
@@ -121,6 +128,45 @@ int sot_mt_bits(sot_ctx *ctx, const void *delta, uint64_t *a_out, uint64_t *b_ou
  * MulTriples live in host memory, gmw/src/mul_triple/mod.rs:30-35): this is what a multi-GPU party hands to the
  * RCCL all-gather that reassembles its MT store from the per-GPU instances. */
 int sot_mt_bits_to_device(sot_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+
+/* ---- one expansion sharded over the GPUs of a node (no counterpart in the reference, whose parallelism is
+ * rayon threads: tree groups pprf.rs:128, bit rows quasi_cyclic_encode.rs:35-46, column tiles :140-151) -------------
+ * One process per GPU, `world` in {2, 4, 8}. Rank r expands the tree sets [set0, set0 + nsets_local) (or all of them
+ * when ggm_replicated != 0), encodes bit rows [r * 128 / world, (r + 1) * 128 / world) of BOTH roles in one pass and
+ * hashes the outputs [k0, k0 + n_local). The library moves no bytes between GPUs; the host runs two all-to-alls (RCCL)
+ * on DEVICE buffers between the calls below, peer order = rank order, equal counts per peer:
+ *     sot_sender_expand + sot_receiver_expand          (own tree sets; TreeGrp arrays: only this rank's groups are
+ *                                                       written / read, the flat layout is unchanged)
+ *     sot_shard_pack_leaves(send)   -> all-to-all, x1_bytes_per_peer to each peer -> sot_shard_unpack_leaves(recv)
+ *       (ggm_replicated: sot_shard_local_leaves instead, no exchange)
+ *     sot_shard_qc_encode(points, send2)  -> all-to-all, x2_bytes_per_peer to each peer -> sot_shard_unpack_encoded(recv2)
+ *     sot_sender_hash / sot_receiver_hash / sot_mt_bits / sot_download_encoded / sot_mt_bits_to_device / sot_and_circ_*
+ *       now work on this rank's n_local outputs; concatenated in rank order (MT words: chunk / 64 words per rank and
+ *       vector) they are bit-identical to the one-GPU context's results for the same inputs. */
+typedef struct sot_shard_info {
+    uint32_t rank, world;
+    uint32_t set0, nsets_local; /* tree sets (groups of 8 trees) this rank expands */
+    uint32_t ggm_replicated;
+    uint32_t rows_per_rank;     /* 128 / world */
+    uint64_t k0, n_local;       /* outputs of the hash stage owned by this rank */
+    uint64_t chunk;             /* outputs per rank (multiple of 64); k0 = rank * chunk */
+    uint64_t x1_bytes_per_peer; /* exchange #1 message size; send / recv buffers hold world of them */
+    uint64_t x2_bytes_per_peer; /* exchange #2 message size */
+} sot_shard_info;
+int sot_ctx_create_sharded(uint64_t n, uint64_t scaler, int device, uint32_t rank, uint32_t world, int ggm_replicated,
+                           sot_ctx **out);
+int sot_shard_info_get(const sot_ctx *ctx, sot_shard_info *out);
+/* leaf slices of this rank's tiles for every peer -> send_dev (device, world * x1_bytes_per_peer); synchronous */
+int sot_shard_pack_leaves(sot_ctx *ctx, void *send_dev);
+/* recv_dev (device, world * x1_bytes_per_peer, message of rank r at r * x1_bytes_per_peer) -> slot Blocks */
+int sot_shard_unpack_leaves(sot_ctx *ctx, const void *recv_dev);
+/* ggm_replicated: cut this rank's rows out of the locally expanded leaves */
+int sot_shard_local_leaves(sot_ctx *ctx);
+/* dual_encode + dual_encode2(packed) of this rank's bit rows of both roles -> send_dev (device,
+ * world * x2_bytes_per_peer): the send buffer of exchange #2; synchronous */
+int sot_shard_qc_encode(sot_ctx *ctx, const uint64_t *points, uint64_t npoints, void *send_dev);
+/* recv_dev (device, world * x2_bytes_per_peer) -> this rank's n_local whole Blocks B and A */
+int sot_shard_unpack_encoded(sot_ctx *ctx, const void *recv_dev);
 
 /* ---- FLUTE function-dependent setup: AND layers over the expanded triples ------------------ */
 /* LutSetupProvider::setup (gmw/src/protocols/aby2_lut.rs:699-783) evaluates, with BooleanGmw and multiplication

@@ -365,3 +365,42 @@ def test_receiver_hash_leaves_the_mt_store_alone(fa, orc):
             e.mt_bits_to_device(buf.data_ptr(), buf.numel() * 8)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n,T,seed", [(1000, 2, 42), (40000, 3, 8), (1 << 20, 4, 20)])
+def test_receiver_unpacked_choice_bits(fa, orc, n, T, seed):
+    """ChoiceBitPacking::False (quasi_cyclic_encode.rs:65-68,104-117), the mode of the reference's own
+    correlated_silent_ot test (silent_ot/mod.rs:836-872): A keeps all 128 rows of rT, the choice vector C is a separate
+    product. Bit-exact against the oracle, then check_correlated with the explicit choice vector (mod.rs:744-777: no
+    masking of bit 0), and the hash of an unpacked A is refused."""
+    from flute_amd.lib import SotError
+    conf, msg2, msg, choices, delta, prg = _inputs(orc, n, seed)
+    delta = np.array([M64, M64], dtype=np.uint64)  # Block::all_ones() as in the reference test
+    eng = fa.Engine(n)
+    try:
+        snd = fa.Sender.new_with_silent_base_ots(eng, msg2, T)
+        rcv = fa.Receiver.new_with_silent_base_ots(eng, msg, choices, T)
+        B = snd.correlated_silent_send(delta, prg)
+        A, Cv = rcv.correlated_silent_receive(snd.tree_groups, choice_bit_packing=False)
+        o_rT_s, o_sums, o_last = orc.pprf_sender_expand(conf, msg2, delta, prg, T)
+        o_rT_r = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
+        o_A, o_C = orc.qc_dual_encode2(conf, o_rT_r, rcv.S, packed=False)
+        assert np.array_equal(B, orc.qc_dual_encode(conf, o_rT_s))
+        assert np.array_equal(A, o_A), "unpacked A"
+        assert Cv.dtype == np.uint8 and np.array_equal(Cv, o_C), "choice vector C"
+        assert 0 < Cv.sum() < n
+        # check_correlated, choice = Some(C): A == B ^ C * delta on all 128 bits
+        want = B.copy()
+        want[Cv.astype(bool)] ^= delta
+        assert np.array_equal(A, want)
+        with pytest.raises(SotError):
+            eng.receiver_hash()
+        with pytest.raises(SotError):
+            eng.mt_bits(delta)
+        # the packed mode on the same leaves: bit 0 of A is C, the other 127 rows are the same
+        A_packed = rcv.correlated_silent_receive(snd.tree_groups)
+        assert np.array_equal(A_packed[:, 0] & np.uint64(1), Cv.astype(np.uint64))
+        assert np.array_equal(A_packed[:, 0] >> np.uint64(1), A[:, 0] >> np.uint64(1)) and np.array_equal(A_packed[:, 1], A[:, 1])
+        eng.receiver_hash()  # allowed again
+    finally:
+        eng.close()
