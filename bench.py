@@ -5,8 +5,12 @@ A "step" is one SilentMtProvider::precompute_mts equivalent (gmw/src/mul_triple/
 what flute_benchmark's `time_silent_ots_ms` covers, bench.rs:274-278) for n = 2^24 requested OTs:
 one sender expansion + one receiver expansion (GGM/PPRF -> QuasiCyclic encode) + fused CR hashes and
 MT-bit derivation, after the base-OT seeds exist. value = 2n * steps / time ("times two because both
-parties generate this amount", bench.rs:271-272), aggregated over ranks (each rank runs independent
-instances: weak scaling, no data-path collective).
+parties generate this amount", bench.rs:271-272).
+N > 1 (default --mode strong): that ONE expansion is sharded over the ranks -- tree sets in the GGM stage, bit rows of
+both roles in the QC stage, output ranges in the hash stage, two RCCL all-to-alls between the stages and an all-gather
+of the MT words (csrc/shard.hip, flute_amd/dist.py); the gathered result is bit-identical to the one-GPU result, which
+rank 0 checks after the timed region (--no-verify to skip). --mode weak: independent instances per rank, value
+aggregated over ranks.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched through torch.distributed.run)
 
@@ -133,6 +137,132 @@ def load_pmc():
         return None
 
 
+def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
+    """N > 1, one expansion over all ranks (BASELINE config 3). Every rank holds the same inputs (one party's base OTs,
+    delta, seeds: in the reference they come from the base-OT phase and the party's RNG, both outside the hot path)."""
+    replicate = args.ggm == "replicate" or (args.ggm == "auto" and world == 2)
+    eng = fa.ShardedEngine(n, rank, world, device=local_rank, ggm_replicated=replicate)
+    conf = eng.conf
+    rng = np.random.default_rng(fd.instance_seed(0))  # the SAME instance on every rank
+    x = fa.fake_base(conf, rng)
+    y = fa.fake_base(conf, rng)
+    delta, seed, delta_peer, seed_peer = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    # the peer's TreeGrps for direction Y (received over mpc_channel in the reference), for the tree sets this rank expands
+    tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads)
+    pts = eng.points(y[2])
+    pipe = fd.ShardedPipeline(eng)
+    xch = {"ms": 0.0, "on": False}
+    base_exchange = pipe.exchange
+
+    def timed_exchange(s, r):  # wall time of the collectives (stream-synchronous: the engine waits for them anyway)
+        if not xch["on"]:
+            return base_exchange(s, r)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = base_exchange(s, r)
+        torch.cuda.synchronize()
+        xch["ms"] += (time.perf_counter() - t) * 1e3
+        return out
+    pipe.exchange = timed_exchange
+    res = {}
+
+    def step():
+        pipe.expand(x[0], delta, seed, args.threads, y[1], y[2], *tg_y)
+        pipe.exchange_leaves()
+        pipe.encode(pts)
+        res["mt"] = pipe.mt_bits(delta, gather=not args.no_gather)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        fd.barrier(world)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = fd.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    prof, dt_prof = {}, None
+    if not args.no_prof:
+        eng.prof_reset()
+        eng.prof_enable(True)
+        xch["on"] = True
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_prof = time.perf_counter() - t1
+        eng.prof_enable(False)
+        xch["on"] = False
+        prof = eng.prof_read()
+    verified = None
+    if not args.no_verify and not args.no_gather:
+        # bit-for-bit against the one-GPU context on rank 0's GPU (every rank holds the same gathered words)
+        ok = 1
+        if rank == 0:
+            ref = fa.Engine(n, device=local_rank)
+            try:
+                tg_full = ref.sender_expand(y[0], delta_peer, seed_peer, args.threads)  # the peer's TreeGrps, all groups
+                ref.sender_expand(x[0], delta, seed, args.threads)
+                ref.qc_encode(0)
+                ref.receiver_expand(y[1], y[2], *tg_full)
+                ref.qc_encode(1, pts)
+                want = np.stack(ref.mt_bits(delta))
+            finally:
+                ref.close()
+            got = res["mt"].cpu().numpy().view(np.uint64)[:, :want.shape[1]]
+            ok = int(np.array_equal(got, want))
+        t = torch.tensor([ok], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        verified = bool(t.item())
+    if rank == 0:
+        info = eng.info
+        out = {
+            "metric": "random OTs/sec for 2^%d silent-OT expansion (sender+receiver per party, MT bits)" % args.log2n,
+            "value": 2.0 * n * args.steps / dt, "unit": "OTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_profiled": dt_prof / args.steps * 1e3 if dt_prof else None, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 bitwise (GF(2)/AES, 128-bit blocks)", "data": "synthetic",
+            "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, ONE n=2^%d expansion (sender + receiver "
+                                   "instance, MT bits) sharded over %d GPUs" % (args.log2n, world),
+                       "P": conf.P, "trees": conf.parts, "depth": conf.depth, "threads_T": args.threads,
+                       "sharding": "GGM: %s; QC: %d bit rows of both roles per rank; hash/MT: %d outputs per rank; "
+                                   "all-to-all #1 %d B, #2 %d B per peer and step; MT words all-gathered%s" % (
+                                       "replicated on every rank (no exchange #1)" if replicate else
+                                       "tree sets %d..%d of %d on rank 0" % (info.set0, info.set0 + info.nsets_local - 1,
+                                                                             conf.parts // 8),
+                                       info.rows_per_rank, info.chunk, info.x1_bytes_per_peer, info.x2_bytes_per_peer,
+                                       "" if not args.no_gather else " (skipped)")},
+            "sharded_equals_one_gpu": verified,
+        }
+        if prof:
+            per_step = {k: (ms / args.steps, cnt // args.steps) for k, (ms, cnt) in prof.items()}
+            qc_ms = sum(ms for k, (ms, _) in per_step.items() if k in QC_KERNELS)
+            dom_name, (dom_ms, dom_cnt) = max(per_step.items(), key=lambda kv: kv[1][0])
+            # this rank's share of the algorithmic bytes: 48 B/OT x n x 2 directions / world, in ONE pass of the stage
+            alg = QC_BYTES_PER_OT * n * 2.0 / world
+            achieved = alg / (qc_ms * 1e-3) / 1e9 if qc_ms else None
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                "kernel": dom_name, "kernel_avg_ms": dom_ms / max(dom_cnt, 1), "kernel_launches_per_step": dom_cnt,
+                "basis": "rank 0, QC-encode stage: 48 B/OT x n x 2 directions / %d ranks / summed device time of the "
+                         "stage's kernels per step (%.3f ms); traffic not collected in multi-GPU runs" % (world, qc_ms)}
+            ggm_ms = sum(ms for k, (ms, _) in per_step.items() if k in GGM_KERNELS)
+            out["stages"] = {"ggm_expand_ms": ggm_ms, "qc_encode_ms": qc_ms,
+                             "shard_pack_unpack_ms": sum(per_step.get(k, (0.0, 0))[0] for k in ("k_shard_pack", "k_shard_unpack")),
+                             "hash_mt_bits_ms": per_step.get("k_mt_bits", (0.0, 0))[0],
+                             "exchanges_wall_ms": xch["ms"] / args.steps}
+            out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +280,13 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsals on a 1-GPU box)")
     ap.add_argument("--lut-log2b", type=int, default=16, help="FLUTE setup section: 2^b sbox8 instances (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--mode", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = ONE expansion sharded over the ranks (default), weak = one instance per rank")
+    ap.add_argument("--ggm", choices=("auto", "shard", "replicate"), default="auto",
+                    help="strong mode: tree sets sharded over the ranks + exchange #1, or every rank expands all trees "
+                         "(auto: replicate at 2 ranks, where one xGMI link would carry the whole leaf exchange)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="strong mode: skip the bit-for-bit check of the gathered MT words against a one-GPU context")
     args = ap.parse_args()
 
     from flute_amd import dist as fd
@@ -166,6 +303,9 @@ def main():
 
     import flute_amd as fa
     n = 1 << args.log2n
+    if world > 1 and args.mode == "strong":
+        strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n)
+        return
     eng = fa.Engine(n, device=local_rank)
     conf = eng.conf
     rng = np.random.default_rng(fd.instance_seed(rank))
@@ -240,7 +380,8 @@ def main():
             "metric": "random OTs/sec for 2^%d silent-OT expansion (sender+receiver per party, MT bits)" % args.log2n,
             "value": value, "unit": "OTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "ms_per_step_profiled": dt_prof / args.steps * 1e3 if dt_prof else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_profiled": dt_prof / args.steps * 1e3 if dt_prof else None, "higher_is_better": True,
+            "scaling": "weak" if world > 1 else "strong", "vs_baseline": None,
             "dtype": "u32 bitwise (GF(2)/AES, 128-bit blocks)", "data": "synthetic",
             "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, n=2^%d random OTs per direction, "
                                    "sender+receiver expansion + MT bits on each GPU" % args.log2n,

@@ -103,12 +103,13 @@ def gather_sharded_words(local, world):
         return local
     import torch.distributed as dist
     flat = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    src = local.contiguous().reshape(-1)  # 1-D in, 1-D out: the concatenated form on every backend
     if local.is_cuda and dist.get_backend() == "gloo":
         h = torch.empty(flat.numel(), dtype=local.dtype)
-        dist.all_gather_into_tensor(h, local.contiguous().cpu())
+        dist.all_gather_into_tensor(h, src.cpu())
         flat.copy_(h)
     else:
-        dist.all_gather_into_tensor(flat, local.contiguous())
+        dist.all_gather_into_tensor(flat, src)
     return flat.reshape(world, 3, -1).permute(1, 0, 2).reshape(3, -1)
 
 

@@ -65,3 +65,46 @@ def test_two_rank_plumbing():
     assert m0 != m1  # different instances per rank
     assert dt0 == dt1 == 1.5  # max over ranks
     assert v0 == v1 == 2 * 2.0 * (1 << 24) * 10 / 1.5
+
+
+def _worker_strong(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    from flute_amd import dist as fd
+    d = fd.init("gloo", rank, world)
+    # exchange: message q of rank r = the bytes (r, q, i): after the all-to-all message r of rank q holds (r, q, i)
+    m = 4096
+    send = torch.empty(world * m, dtype=torch.uint8)
+    for peer in range(world):
+        send[peer * m:(peer + 1) * m] = torch.from_numpy(
+            ((np.arange(m) * 7 + 31 * rank + 101 * peer) % 251).astype(np.uint8))
+    recv = fd.all_to_all_bytes(send, world)
+    ok = all(np.array_equal(recv[src * m:(src + 1) * m].numpy(),
+                            ((np.arange(m) * 7 + 31 * src + 101 * rank) % 251).astype(np.uint8)) for src in range(world))
+    # MT words of a sharded expansion: [3, chunk / 64] per rank -> [3, world * chunk / 64], vector-major
+    nwl = 5
+    local = torch.from_numpy((np.arange(3 * nwl, dtype=np.int64) + 1000 * rank).reshape(3, nwl))
+    g = fd.gather_sharded_words(local, world).numpy()
+    q.put((rank, ok, g.tobytes()))
+    d.destroy_process_group()
+
+
+def test_two_rank_strong_scaling_collectives():
+    """all_to_all_bytes (exchange #1 / #2 of one sharded expansion) and gather_sharded_words over gloo, world size 2"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    nwl = 5
+    want = np.concatenate([(np.arange(3 * nwl, dtype=np.int64) + 1000 * r).reshape(3, nwl) for r in range(world)], axis=1)
+    for rank, ok, g in res:
+        assert ok, "all-to-all delivered the wrong messages on rank %d" % rank
+        assert g == want.tobytes()
