@@ -37,35 +37,67 @@ QC_KERNELS = ("k_clear_lsb", "k_qc_load", "k_conv_fwd", "k_conv_fwd_tile", "k_ff
               "k_ifft_mid", "k_ifft_top", "k_conv_inv_tile", "k_conv_inv", "k_qc_store", "k_qc_final")
 
 
-def cpu_baseline(log2n_sample, T):
-    """The CPU oracle (a port of the zappot/gmw path; the GF(2)[x] product runs the REFERENCE's own
-    bitpolymul2 C when oracle/_ref is present) timed on this host's cores for a smaller full pipeline."""
+def cpu_baseline(log2n_sample, T_gpu):
+    """The CPU oracle (a port of the zappot/gmw path; the GF(2)[x] product runs the REFERENCE's own bitpolymul2 C when
+    oracle/_ref is present) timed on this host's cores with the reference's thread policy: SilentMtProvider gives each
+    direction a pool of available_parallelism() / 2 threads and runs both directions concurrently
+    (gmw/src/mul_triple/silent_ot.rs:47,87-91); the GGM workers stride the tree groups (pprf.rs:128), the 128 QC rows
+    and the output transposes run on the same pool, the hashes and the MT-bit loop are single-threaded as in the
+    reference (silent_ot/mod.rs:275-287, silent_ot.rs:93-111)."""
+    import threading
     from oracle import sot_oracle as orc
     orc.build()
     ref_mul = orc.use_reference_multiplier(True)
     n = 1 << log2n_sample
     conf = orc.configure(n)
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = max(1, min(cores, os.cpu_count() or cores))
+    T = max(1, cores // 2)
     rng = np.random.default_rng(123)
     x = orc.fake_base(conf, rng)
     y = orc.fake_base(conf, rng)
     delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
     seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
     # peer's sender for direction Y (not timed): gives the TreeGrps our receiver consumes
+    orc.set_num_threads(cores)
     _, sums_y, last_y = orc.pprf_sender_expand(conf, y[0], delta, seed, T)
+    out = {}
+
+    def send():
+        orc.set_num_threads(T)
+        out["s"] = orc.random_silent_send(conf, x[0], delta, seed, T)[0]
+
+    def recv():
+        orc.set_num_threads(T)
+        r = orc.random_silent_receive(conf, y[1], y[2], sums_y, last_y)
+        out["r"] = (r[0], r[1])
+
     t0 = time.perf_counter()
-    smsgs, _, _, _, _ = orc.random_silent_send(conf, x[0], delta, seed, T)
-    rmsgs, ch, _, _ = orc.random_silent_receive(conf, y[1], y[2], sums_y, last_y)
-    orc.mt_bits(smsgs.reshape(-1, 2), rmsgs, ch)
+    th = [threading.Thread(target=send), threading.Thread(target=recv)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    orc.mt_bits(out["s"].reshape(-1, 2), out["r"][0], out["r"][1])
     dt = time.perf_counter() - t0
+    # the same work with ONE worker per direction, directions one after the other (T = 1: what a single core does)
+    orc.set_num_threads(1)
+    t1 = time.perf_counter()
+    s1 = orc.random_silent_send(conf, x[0], delta, seed, 1)[0]
+    _, sy1, ly1 = None, sums_y, last_y
+    r1 = orc.random_silent_receive(conf, y[1], y[2], sy1, ly1)
+    orc.mt_bits(s1.reshape(-1, 2), r1[0], r1[1])
+    dt1 = time.perf_counter() - t1
+    orc.set_num_threads(cores)
     orc.use_reference_multiplier(False)
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    cores = min(cores, os.cpu_count() or cores)
     return {
         "value": 2 * n / dt, "unit": "OTs/s", "cores": cores, "kind": "port",
-        "sample": ("full precompute_mts pipeline (sender+receiver expand, QC encode, hashes, MT bits) at "
-                   "n=2^%d, T=%d; GGM/transposes single-threaded, 128 QC rows over OpenMP threads; "
-                   "GF(2)[x] product = %s; %.2f s wall") % (
-            log2n_sample, T, "reference bitpolymul_2_128 (oracle/_ref)" if ref_mul else "oracle Karatsuba+PCLMUL", dt),
+        "single_thread_value": 2 * n / dt1,
+        "sample": ("full precompute_mts pipeline (sender+receiver expand, QC encode, hashes, MT bits) at n=2^%d with the "
+                   "reference's thread policy: both directions concurrently, T = cores/2 = %d workers each (GGM groups, "
+                   "128 QC rows, transposes), hashes and MT bits single-threaded; GF(2)[x] product = %s; %.2f s wall "
+                   "(one worker, directions in sequence: %.2f s)") % (
+            log2n_sample, T, "reference bitpolymul_2_128 (oracle/_ref)" if ref_mul else "oracle Karatsuba+PCLMUL", dt, dt1),
     }
 
 
@@ -271,8 +303,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="requested OTs per direction = 2^log2n")
     ap.add_argument("--threads", type=int, default=4,
                     help="rayon pool size the reference would use (roots depend on it, pprf.rs:115)")
-    ap.add_argument("--cpu-log2n", type=int, default=24,
-                    help="CPU baseline sample size (2^24 = the GPU workload itself, about 10-20 s on 16 cores)")
+    ap.add_argument("--cpu-log2n", type=int, default=22,
+                    help="CPU baseline sample size (2^22: about 10-20 s in all on 16 cores, the one-worker leg included)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")

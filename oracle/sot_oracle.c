@@ -81,6 +81,11 @@ static const uint8_t SBOX[256] = {
     0x69, 0xd9, 0x8e, 0x94, 0x9b, 0x1e, 0x87, 0xe9, 0xce, 0x55, 0x28, 0xdf, 0x8c, 0xa1, 0x89, 0x0d, 0xbf, 0xe6, 0x42,
     0x68, 0x41, 0x99, 0x2d, 0x0f, 0xb0, 0x54, 0xbb, 0x16};
 
+/* OpenMP team size of the CALLING thread (a per-thread setting): the CPU baseline runs the sender and the receiver
+ * direction from two host threads with available_parallelism() / 2 workers each, gmw/src/mul_triple/silent_ot.rs:47,87-91 */
+void orc_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
+
 static int g_force_portable = 0;
 void orc_force_portable(int on) { g_force_portable = on; }
 
@@ -403,11 +408,20 @@ int orc_pprf_sender_expand(const orc_conf *c, const orc_block *base_ots, orc_blo
     aes_init(&aes[1], KEY_GGM1);
     aes_init(&kh, KEY_HASH);
     memset(out_rT, 0, 128 * cols * sizeof(orc_block)); /* pprf.rs:93 */
-    orc_block *tree = (orc_block *)malloc(((size_t)8 << (depth + 1)) * sizeof(orc_block));
-    orc_block(*sums)[8] = (orc_block(*)[8])malloc(2 * depth * 8 * sizeof(orc_block));
-    if (!tree || !sums) return -2;
-
+    int failed = 0;
+    /* pprf.rs:267-276: (0..num_threads).into_par_iter().for_each(routine) on the instance's rayon pool: the logical
+     * workers run on as many OS threads as orc_set_num_threads() gave this caller (1 by default); every worker owns its
+     * tree scratch (pprf.rs:116-126) and writes disjoint columns of the output (the reference takes a Mutex, :261) */
+#pragma omp parallel for schedule(dynamic, 1)
     for (uint64_t t = 0; t < num_threads; t++) {
+        orc_block *tree = (orc_block *)malloc(((size_t)8 << (depth + 1)) * sizeof(orc_block));
+        orc_block(*sums)[8] = (orc_block(*)[8])malloc(2 * depth * 8 * sizeof(orc_block));
+        if (!tree || !sums) {
+            failed = 1;
+            free(tree);
+            free(sums);
+            continue;
+        }
         /* pprf.rs:115: AesRng::from_seed(seed ^ thread_idx) */
         orc_block s = seed;
         s.w[0] ^= t;
@@ -445,10 +459,10 @@ int orc_pprf_sender_expand(const orc_conf *c, const orc_block *base_ots, orc_blo
             /* pprf.rs:259-263 */
             pprf_copy_out(tree + 8 * (((uint64_t)1 << depth) - 1), (uint64_t)1 << depth, out_rT, cols, pnt, g);
         }
+        free(tree);
+        free(sums);
     }
-    free(tree);
-    free(sums);
-    return 0;
+    return failed ? -2 : 0;
 }
 
 int orc_pprf_receiver_expand(const orc_conf *c, const orc_block *base_ots, const uint8_t *choices,
@@ -460,13 +474,20 @@ int orc_pprf_receiver_expand(const orc_conf *c, const orc_block *base_ots, const
     aes_init(&aes[1], KEY_GGM1);
     aes_init(&kh, KEY_HASH);
     memset(out_rT, 0, 128 * cols * sizeof(orc_block));
-    orc_block *tree = (orc_block *)calloc((size_t)8 << (depth + 1), sizeof(orc_block));
-    if (!tree) return -2;
     /* pprf.rs:315: plain points */
     uint64_t *points = (uint64_t *)malloc(pnt * sizeof(uint64_t));
     for (uint64_t t = 0; t < pnt; t++) points[t] = orc_get_active_path(choices + t * depth, depth);
-
-    for (uint64_t g = 0; g < pnt; g += 8) {
+    int failed = 0;
+    /* pprf.rs:347-372,546-555: the receiver's workers take tree groups as their messages arrive; here every group is a
+     * task on the caller's OpenMP team (the result does not depend on the worker count) */
+#pragma omp parallel
+    {
+    orc_block *tree = (orc_block *)calloc((size_t)8 << (depth + 1), sizeof(orc_block));
+    if (!tree) failed = 1;
+#pragma omp for schedule(dynamic, 1)
+    for (uint64_t grp_i = 0; grp_i < pnt / 8; grp_i++) {
+        if (!tree) continue;
+        const uint64_t g = 8 * grp_i;
         uint64_t grp = g / 8;
         const orc_block *gs = tg_sums + grp * 2 * (depth - 1) * 8; /* [keep][d][8] */
         orc_block my_sums[2][8];
@@ -519,9 +540,10 @@ int orc_pprf_receiver_expand(const orc_conf *c, const orc_block *base_ots, const
         }
         pprf_copy_out(level, (uint64_t)1 << depth, out_rT, cols, pnt, g);
     }
-    free(points);
     free(tree);
-    return 0;
+    }
+    free(points);
+    return failed ? -2 : 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -694,8 +716,9 @@ void orc_qc_a_poly(const orc_conf *c, uint64_t *a_out) {
     free(tmp);
 }
 
-static orc_block *g_cmodp = NULL;
-static uint64_t g_cmodp_rows = 0, g_cmodp_cols = 0;
+/* per calling thread: two host threads run the two directions concurrently (bench.py cpu_baseline) */
+static __thread orc_block *g_cmodp = NULL;
+static __thread uint64_t g_cmodp_rows = 0, g_cmodp_cols = 0;
 const orc_block *orc_last_cmodp(uint64_t *rows, uint64_t *cols) {
     *rows = g_cmodp_rows;
     *cols = g_cmodp_cols;
@@ -733,10 +756,11 @@ static int qc_encode_common(const orc_conf *c, const orc_block *rT, const orc_bl
     g_cmodp = (orc_block *)calloc(128 * nb, sizeof(orc_block));
     g_cmodp_rows = 128;
     g_cmodp_cols = nb;
+    orc_block *const cmodp = g_cmodp; /* the parallel regions below read a plain pointer, not the thread-local */
 #pragma omp parallel for schedule(dynamic)
     for (int r = 0; r < 128; r++) {
         const orc_block *row = (sb && packed && r == 0) ? sb : rT + (uint64_t)r * c->cols;
-        qc_reduce(c, a, g_cmodp + (uint64_t)r * nb, row);
+        qc_reduce(c, a, cmodp + (uint64_t)r * nb, row);
     }
     if (sb && !packed) {
         /* quasi_cyclic_encode.rs:104-117 */
@@ -748,7 +772,7 @@ static int qc_encode_common(const orc_conf *c, const orc_block *rT, const orc_bl
     }
     uint64_t num_blocks = (c->n + 127) / 128 * 128;
     orc_block *full = (orc_block *)calloc(c->N2 > num_blocks ? c->N2 : num_blocks, sizeof(orc_block));
-    qc_copy_out(full, num_blocks, g_cmodp, nb);
+    qc_copy_out(full, num_blocks, cmodp, nb);
     memcpy(out, full, c->n * sizeof(orc_block));
     free(full);
     free(a);

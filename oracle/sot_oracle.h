@@ -123,6 +123,11 @@ void orc_receiver_hash(orc_block *A, uint64_t n, uint64_t *choice_words);
 void orc_mt_bits(const orc_block *send_msgs /*2n*/, const orc_block *recv_msgs /*n*/, const uint64_t *recv_choice_words,
                  uint64_t n, uint64_t *a, uint64_t *b, uint64_t *c);
 
+/* OpenMP team size for the calling host thread (per-thread); the GGM workers, the 128 QC rows and the output
+ * transposes run on that team */
+void orc_set_num_threads(int n);
+int orc_get_max_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,8 @@ def lib():
         L.orc_receiver_hash.argtypes = [P, u64, P]
         L.orc_mt_bits.argtypes = [P, P, P, u64, P, P, P]
         L.orc_force_portable.argtypes = [C.c_int]
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_get_max_threads.restype = C.c_int
         L.orc_have_aesni.restype = C.c_int
         _LIB = L
     return _LIB
@@ -110,6 +112,15 @@ def use_reference_multiplier(on=True):
         return False
     lib().orc_set_external_mul(C.cast(r.bitpolymul_2_128, C.c_void_p) if on else None)
     return True
+
+
+def set_num_threads(n):
+    """OpenMP team size for the CALLING Python thread's oracle calls (GGM workers, QC rows, transposes)."""
+    lib().orc_set_num_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_get_max_threads())
 
 
 def _p(a):
