@@ -14,10 +14,10 @@ def dig(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.fixture(scope="module")
-def gold():
-    meta = json.load(open(os.path.join(HERE, "golden", "silent_ot_n1000.json")))
-    data = np.load(os.path.join(HERE, "golden", "silent_ot_n1000.npz"), allow_pickle=False)
+@pytest.fixture(scope="module", params=["silent_ot_n1000", "silent_ot_n65536"])
+def gold(request):
+    meta = json.load(open(os.path.join(HERE, "golden", request.param + ".json")))
+    data = np.load(os.path.join(HERE, "golden", request.param + ".npz"), allow_pickle=False)
     return meta, data
 
 
@@ -33,8 +33,27 @@ def test_oracle_reproduces_golden(orc, gold):
            "a_poly": dig(orc.qc_a_poly(conf)), "cmodp_row0": dig(cm[0]), "cmodp_row1": dig(cm[1]),
            "cmodp_row127": dig(cm[127]), "B": dig(B), "A": dig(A), "sender_msgs": dig(smsgs),
            "receiver_msgs": dig(rmsgs), "choice_words": dig(ch), "mt_a": dig(a), "mt_b": dig(b), "mt_c": dig(c)}
+    A_un, C_un = orc.qc_dual_encode2(conf, rT_r, orc.pprf_points(conf, d["choices"]), packed=False)
+    got["A_unpacked"], got["C_unpacked"] = dig(A_un), dig(C_un)
     assert got == meta["sha256"]
     assert np.array_equal(B[:64], d["B_head"]) and np.array_equal(A[:64], d["A_head"])
+    assert np.array_equal(B[-64:], d["B_tail"]) and np.array_equal(A[-64:], d["A_tail"])
+
+
+def test_product_vectors(orc):
+    """three raw GF(2)[x] products (n64 = 264, 16 386, 262 146: the row lengths of n = 1000, 2^20, 2^24) against the
+    committed digests; with oracle/_ref present the reference's own bitpolymul_2_128 must give the same words"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden import product_operands
+    want = json.load(open(os.path.join(HERE, "golden", "gf2x_products.json")))
+    for key, w in want.items():
+        a, b = product_operands(int(key))
+        c = orc.gf2x_mul(a, b)
+        assert dig(c) == w["sha256"], key
+        assert [int(x) for x in c[:8]] == w["head"] and [int(x) for x in c[-8:]] == w["tail"]
+        if orc.ref_lib() is not None:
+            assert dig(orc.ref_bitpolymul_2_128(a, b)) == w["sha256"], "reference bitpolymul_2_128 at n64=" + key
 
 
 @pytest.mark.gpu
@@ -59,5 +78,7 @@ def test_gpu_reproduces_golden(gold):
         assert dig(rmsgs) == want["receiver_msgs"] and dig(ch) == want["choice_words"]
         a, b, c = eng.mt_bits(d["delta"])
         assert (dig(a), dig(b), dig(c)) == (want["mt_a"], want["mt_b"], want["mt_c"])
+        Cv = eng.qc_encode2(eng.points(d["choices"]), packed=False)
+        assert dig(eng.download_encoded(1)) == want["A_unpacked"] and dig(Cv) == want["C_unpacked"]
     finally:
         eng.close()
