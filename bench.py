@@ -101,13 +101,34 @@ def cpu_baseline(log2n_sample, T_gpu):
     }
 
 
+def aes128_workloads(fa, n, ms_per_step, lut):
+    """BASELINE configs 4 and 5 in numbers: what one step's 2^k-triple device store buys, and the rates. Both paths draw
+    on the same store; FLUTE's function-dependent setup needs 49 400 triples per AES-128 (200 sbox8 LUTs x 247 subset
+    products), Boolean GMW 6 400 (the Bristol circuit's AND gates)."""
+    mts_per_s = n / (ms_per_step * 1e-3)  # this party's triples per second at the measured step time
+    out = {
+        "bristol_and_gates_per_aes": fa.AES128_BRISTOL_AND_GATES,
+        "bristol_source": "crates/flute_benchmark/Baseline/bristol/aes_128.bristol (36663 gates, 6400 AND)",
+        "flute_sbox8_luts_per_aes": fa.AES128_SBOXES, "flute_setup_mts_per_aes": fa.AES128_LUT_SETUP_MTS,
+        "gmw_aes_instances_per_store": n // fa.AES128_BRISTOL_AND_GATES,
+        "flute_aes_instances_per_store": n // fa.AES128_LUT_SETUP_MTS,
+        "gmw_aes_instances_per_s_mt_supply": mts_per_s / fa.AES128_BRISTOL_AND_GATES,
+        "flute_aes_instances_per_s_mt_supply": mts_per_s / fa.AES128_LUT_SETUP_MTS,
+    }
+    if lut and lut.get("value"):
+        # the AND layers themselves (both parties on this GPU): sbox8 instances/s measured above / 200
+        out["flute_aes_instances_per_s_setup_layers"] = lut["value"] / fa.AES128_SBOXES
+        out["flute_setup_batch_aes_instances"] = lut["batch"] / fa.AES128_SBOXES
+    return out
+
+
 def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, log2b, reps):
-    """FLUTE function-dependent setup (aby2_lut.rs:699-783) for 2^log2b instances of to_eval/sbox8.lut (one grouped
+    """FLUTE function-dependent setup (aby2_lut.rs:699-783) for `log2b` (a count) instances of to_eval/sbox8.lut (one grouped
     8-input LUT with 8 outputs = 8 LUT gates, 247 AND gates in 7 layers per instance) on the triples just expanded:
     both parties' AND layers run on this GPU (party 1 = a second engine holding the crossed OT instances), messages
     exchanged device to device. Returns the `lut_setup` object of the bench line."""
     n = eng.conf.n
-    B = 1 << log2b
+    B = log2b  # sbox8 instances
     eng1 = fa.Engine(n, device=eng.device)
     try:
         eng1.sender_expand(y[0], delta_peer, seed_peer, threads)
@@ -310,7 +331,7 @@ def main():
                     help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsals on a 1-GPU box)")
-    ap.add_argument("--lut-log2b", type=int, default=16, help="FLUTE setup section: 2^b sbox8 instances (0 = skip)")
+    ap.add_argument("--lut-log2b", type=int, default=16, help="FLUTE setup section (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--mode", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = ONE expansion sharded over the ranks (default), weak = one instance per rank")
@@ -471,12 +492,15 @@ def main():
                         "frac": rate / VALU_BITOP3_PEAK}
             out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(),
                                                                                 key=lambda kv: -kv[1][0])}
-        if args.lut_log2b and world == 1 and 247 << args.lut_log2b <= n:
+        # FLUTE setup section: as many whole AES-128 instances (200 sbox8 LUTs each) as the step's triples pay for
+        lut_batch = fa.AES128_SBOXES * (n // fa.AES128_LUT_SETUP_MTS) if args.lut_log2b else 0
+        if lut_batch and world == 1:
             try:
                 out["lut_setup"] = lut_setup_bench(fa, eng, x, y, tg_x[0], delta, delta_peer, seed_peer, args.threads,
-                                                   args.lut_log2b, 5)
+                                                   lut_batch, 5)
             except Exception as e:  # a secondary section: never takes the headline line down
                 out["lut_setup"] = {"value": None, "note": "failed: %r" % (e,)}
+        out["aes128"] = aes128_workloads(fa, n, ms_per_step, out.get("lut_setup"))
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, args.threads)

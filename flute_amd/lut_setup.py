@@ -119,6 +119,57 @@ def replicate_setup_circuit(template, batch):
     return SetupCircuit(batch * ni, shift(t.x_src), shift(t.y_src), np.tile(t.depth, batch), outs)
 
 
+# ---- BASELINE configs 4 and 5: AES-128 ---------------------------------------------------------------------------------
+# to_eval/ holds no AES-128 LUT circuit (only sbox8.lut and operators/*), so the "full AES-128 LUT circuit" is composed
+# from sbox8.lut instances: FIPS-197 AES-128 has 10 rounds x 16 SubBytes S-boxes and a key schedule of 10 x 4 S-boxes;
+# with a secret-shared key the schedule runs in-circuit (the Baseline Bristol circuit does the same: its 6 400 AND gates
+# are 200 S-boxes x 32 ANDs). Everything else in AES (ShiftRows, MixColumns, AddRoundKey, Rcon) is XOR-linear: free in
+# FLUTE's setup, which only needs the subset products of every LUT gate's input masks (aby2_lut.rs:699-783).
+AES128_SBOXES = 160 + 40
+SBOX8_SETUP_ANDS = 2 ** 8 - 8 - 1  # 247 per 8-input grouped LUT (its 8 outputs share the subsets through the cache)
+AES128_LUT_SETUP_MTS = AES128_SBOXES * SBOX8_SETUP_ANDS  # 49 400 multiplication triples per AES-128 instance
+# crates/flute_benchmark/Baseline/bristol/aes_128.bristol: header ":1-2" "36663 36919" (gates, wires); 6 400 of the gate
+# lines end in AND (counted in the survey container; the file itself is not copied)
+AES128_BRISTOL_AND_GATES = 6400
+
+
+def aes128_lut_gate_parents(batch):
+    """LUT gates of `batch` AES-128 sub-circuit instances in circuit.interactive_iter() order (bench.rs:367-384 builds
+    the batch as identical sub-circuits; the layer iterator visits LUT layer by LUT layer, inside a layer sub-circuit by
+    sub-circuit, then gate id): LUT layer r - 1 holds round r's 16 SubBytes S-boxes and 4 key-schedule S-boxes of every
+    instance. An S-box is sbox8.lut: 8 LUT gates (one per output bit) over the same 8 parents. Parent ids are
+    (instance, round, sbox, input bit): the wires into different S-boxes are different wires."""
+    parents = []
+    for rnd in range(10):
+        for inst in range(batch):
+            for sb in range(20):  # 0..15 SubBytes, 16..19 key schedule
+                p = tuple((inst, rnd, sb, bit) for bit in range(8))
+                parents.extend([p] * 8)
+    return parents
+
+
+def aes128_setup_circuit(batch):
+    """setup circuit of `batch` AES-128 instances: every S-box has its own 8 inputs, so it equals the sbox8 template
+    replicated 200 * batch times with unit u = (round * batch + instance) * 20 + sbox (tests/test_lut_setup.py checks this
+    against build_setup_circuit(aes128_lut_gate_parents(batch)))"""
+    return replicate_setup_circuit(build_setup_circuit([tuple(range(8))] * 8), AES128_SBOXES * batch)
+
+
+def gmw_and_layers(layer_counts, n_inputs, rng):
+    """A Boolean GMW AND workload in the flat form of sot_and_circ_create: layer l has layer_counts[l] AND gates whose
+    operands are random earlier values (inputs or gates of lower layers). Stands in for the AND layers of a Bristol
+    circuit whose netlist is not shipped (Baseline/bristol/aes_128.bristol: 6 400 AND gates); what it measures and tests
+    is the per-layer triple consumption and evaluation, which depends on the counts only."""
+    x_src, y_src, depth = [], [], []
+    avail = n_inputs
+    for layer, cnt in enumerate(layer_counts):
+        x_src.append(rng.integers(0, avail, cnt))
+        y_src.append(rng.integers(0, avail, cnt))
+        depth.append(np.full(cnt, layer))
+        avail += cnt
+    return SetupCircuit(n_inputs, np.concatenate(x_src), np.concatenate(y_src), np.concatenate(depth), [])
+
+
 class AndCircuit:
     """Device evaluator of a SetupCircuit on an Engine (C ABI sot_and_circ_*). Mirrors Executor<BooleanGmw>:
     per layer compute_msg -> exchange -> evaluate_interactive; MTs come from the end of the engine's MT store."""

@@ -183,3 +183,71 @@ def test_layer_calls_out_of_order_are_refused(fa):
     finally:
         e0.close()
         e1.close()
+
+
+def test_aes128_lut_setup_config4(fa):
+    """BASELINE config 4: FLUTE LUT-triple generation for a full AES-128 LUT circuit (200 sbox8.lut instances per AES,
+    flute_amd.lut_setup.aes128_*), two-party, on the triples of two crossed silent-OT instances: every message and every
+    subset product of one AES instance against the oracle; the store shrinks by 49 400 triples per instance."""
+    from oracle import lut_setup_oracle as lo
+    n = 1 << 16
+    e0, e1, mts = _two_providers(fa, n, 4, 44)
+    try:
+        batch = 1
+        luts = fa.aes128_lut_gate_parents(batch)
+        circ = fa.aes128_setup_circuit(batch)
+        assert circ.n_gates == fa.AES128_LUT_SETUP_MTS == 49400 and circ.n_layers == 7
+        rng = np.random.default_rng(4)
+        ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+        g, out_ids, p0, p1, tr = lo.run_two_party(luts, ins[0], ins[1], mts[0], mts[1])
+        cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((e0, e1))]
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        for layer in range(circ.n_layers):
+            m0, m1 = cs[0].layer_msg(layer), cs[1].layer_msg(layer)
+            (od0, oe0), (od1, oe1), _ = tr[layer]
+            assert np.array_equal(m0[0], od0) and np.array_equal(m0[1], oe0)
+            assert np.array_equal(m1[0], od1) and np.array_equal(m1[1], oe1)
+            cs[0].layer_eval(layer, *m1)
+            cs[1].layer_eval(layer, *m0)
+        and_ids = [i for i, k in enumerate(g.kind) if k == "and"]
+        for c, p in zip(cs, (p0, p1)):
+            assert np.array_equal(c.values()[circ.n_inputs:], p.out[and_ids])
+        assert e0.lib.sot_mt_remaining(e0.h) == n - 49400 == e1.lib.sot_mt_remaining(e1.h)
+        # every LUT gate of every S-box gets its 247 subset products (LutEvalShares, aby2_lut.rs:761-781)
+        shares = cs[0].lut_eval_shares()
+        assert len(shares) == 200 * 8 and all(len(v) == 247 for v in shares)
+    finally:
+        e0.close()
+        e1.close()
+
+
+def test_aes128_bristol_and_layers_config5(fa):
+    """BASELINE config 5: multiplication triples for the Baseline AES-128 Bristol circuit (6 400 AND gates per instance,
+    Baseline/bristol/aes_128.bristol) from the SAME device store the FLUTE LUT path draws on: k instances' AND gates
+    run as Boolean GMW layers (synthetic wiring with the circuit's AND count: the netlist is not shipped), the
+    reconstructed outputs are the ANDs of the reconstructed inputs and the store shrinks by 6 400 per instance --
+    7.7 times fewer triples per AES than the LUT path's 49 400."""
+    n = 1 << 16
+    e0, e1, _ = _two_providers(fa, n, 2, 45)
+    try:
+        k = 5
+        rng = np.random.default_rng(5)
+        circ = fa.gmw_and_layers([fa.AES128_BRISTOL_AND_GATES * k // 40] * 40, 256 * k, rng)
+        assert circ.n_gates == 6400 * k
+        ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+        cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((e0, e1))]
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        for layer in range(circ.n_layers):
+            cs[0].layer_msg(layer, download=False)
+            cs[1].layer_msg(layer, download=False)
+            cs[0].layer_eval_from(layer, cs[1])
+            cs[1].layer_eval_from(layer, cs[0])
+        prod = cs[0].values() ^ cs[1].values()
+        assert np.array_equal(prod[circ.n_inputs:], prod[circ.x_src] & prod[circ.y_src])
+        assert e0.lib.sot_mt_remaining(e0.h) == n - 6400 * k
+        assert n // fa.AES128_BRISTOL_AND_GATES == 10 and n // fa.AES128_LUT_SETUP_MTS == 1
+    finally:
+        e0.close()
+        e1.close()

@@ -100,3 +100,38 @@ def test_replicated_template_equals_generic_builder():
     for name in ("x_src", "y_src", "depth", "exec_order", "layer_counts"):
         assert np.array_equal(getattr(rep, name), getattr(full, name)), name
     assert all(np.array_equal(a, b) for a, b in zip(rep.lut_outputs, full.lut_outputs))
+
+
+def test_aes128_lut_circuit_composition():
+    """BASELINE config 4: AES-128 composed of 200 sbox8.lut instances (160 SubBytes + 40 key schedule). The setup
+    circuit built gate by gate from the LUT gates in interactive_iter() order (LUT layer-major over the batch) equals
+    the replicated sbox8 template, and costs 200 x 247 = 49 400 triples per instance in 7 rounds."""
+    from flute_amd.lut_setup import (AES128_LUT_SETUP_MTS, AES128_SBOXES, aes128_lut_gate_parents,
+                                     aes128_setup_circuit)
+    batch = 2
+    parents = aes128_lut_gate_parents(batch)
+    assert len(parents) == batch * AES128_SBOXES * 8
+    a = build_setup_circuit(parents)
+    b = aes128_setup_circuit(batch)
+    assert a.n_inputs == b.n_inputs == batch * AES128_SBOXES * 8
+    assert a.n_gates == b.n_gates == batch * AES128_LUT_SETUP_MTS == batch * 49400
+    assert a.n_layers == b.n_layers == 7
+    assert np.array_equal(a.x_src, b.x_src) and np.array_equal(a.y_src, b.y_src) and np.array_equal(a.depth, b.depth)
+    assert np.array_equal(a.layer_counts, b.layer_counts)
+    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a.lut_outputs, b.lut_outputs))
+    # one S-box of the composition against the independent oracle builder
+    g, _, _ = lo.build(parents[:8])
+    assert sum(1 for k in g.kind if k == "and") == 247
+
+
+def test_gmw_and_layers_shape():
+    from flute_amd.lut_setup import AES128_BRISTOL_AND_GATES, gmw_and_layers
+    rng = np.random.default_rng(0)
+    counts = [AES128_BRISTOL_AND_GATES // 40] * 40  # 6 400 ANDs in 40 layers
+    c = gmw_and_layers(counts, 256, rng)
+    assert c.n_gates == AES128_BRISTOL_AND_GATES and c.n_layers == 40
+    xs, ys = c.exec_arrays()
+    first = np.concatenate([[0], np.cumsum(c.layer_counts)[:-1]])
+    for l in range(c.n_layers):  # operands come from inputs or lower layers
+        sl = slice(int(first[l]), int(first[l] + c.layer_counts[l]))
+        assert xs[sl].max() < 256 + first[l] and ys[sl].max() < 256 + first[l]
