@@ -71,3 +71,17 @@ def test_mul_triples_split_off_last():
         assert np.array_equal(MulTriples._bits(got, 70), b[130:])
     for got, b in zip((mts.a, mts.b, mts.c), bits):
         assert np.array_equal(MulTriples._bits(got, 130), b[:130])
+
+
+def test_sys_crate_binds_every_declared_symbol():
+    """crates/flute-sot-sys/src/lib.rs (the Rust `-sys` binding a FLUTE maintainer adds) names
+    exactly the symbols of include/flute_sot.h, and its SotConf mirrors sot_conf field for field."""
+    rs = open(os.path.join(ROOT, "crates", "flute-sot-sys", "src", "lib.rs")).read()
+    bound = sorted(set(re.findall(r"pub fn (sot_[A-Za-z0-9_]+)\(", rs)))
+    assert bound == _declared_symbols()
+    from flute_amd.lib import Conf, ShardInfo
+    for struct, cls in (("SotConf", Conf), ("SotShardInfo", ShardInfo)):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rs, flags=re.S).group(1)
+        fields = re.findall(r"pub ([A-Za-z0-9_]+): (u32|u64)", body)
+        want = [(k, "u64" if C.sizeof(t) == 8 else "u32") for k, t in cls._fields_]
+        assert fields == want
