@@ -1621,11 +1621,15 @@ __global__ void __launch_bounds__(MD_THREADS)
         // QC_MIDMASK_LDS: the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and
         // parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
         // registers) and read back as VGPR operands: no scalar-memory stream whose latency the level would expose
-        uint4 mk[4];
+        // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
+        // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
+        u32x16 mk;
         if (QC_MIDMASK_LDS) {
 #pragma unroll
-            for (int b = 0; b < 4; b++)
-                mk[b] = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
+            for (int b = 0; b < 4; b++) {
+                const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
+                mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
+            }
         }
 #pragma unroll
         for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
@@ -1647,7 +1651,7 @@ __global__ void __launch_bounds__(MD_THREADS)
             }
             if (QC_MIDMASK_LDS) {
                 uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
-                R[lane] = mk[b];
+                R[lane] = make_uint4(mk[4 * b + 0], mk[4 * b + 1], mk[4 * b + 2], mk[4 * b + 3]);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
 #pragma unroll
