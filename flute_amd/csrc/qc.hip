@@ -527,6 +527,19 @@ __device__ __forceinline__ void reg_phases(T w[8]) {
     }
 }
 
+// XCD-aware tile order for the kernels whose tiles are row slices (16 or 32 of the 128 rows: 64-B or 128-B pieces of every
+// 512-B word). Workgroup v runs on XCD v % 8 and each XCD has its own L2; with the slice index as the fastest tile
+// coordinate the nrg slices of a word land on nrg different XCDs, every L2 fetches its own sector of each line and HBM sees
+// 64-B requests scattered in time (3.4 TB/s read, 3.7 read+write in tools/micro/gather_copy.hip). Sending the nrg
+// slices of the same words to nrg workgroups of ONE XCD, adjacent in launch order, makes them meet in that L2
+// (6.1 / 5.5 TB/s in the same test). v -> tile index (other coordinates) * nrg + slice; a bijection when ntiles is a
+// multiple of 8 nrg (identity otherwise: small transforms). nrg is a power of two.
+__device__ __forceinline__ uint32_t xcd_slice_order(uint32_t v, uint32_t nrg, uint32_t ntiles) {
+    if (ntiles % (8 * nrg)) return v;
+    const uint32_t x = v & 7u, q = v >> 3;
+    return ((q / nrg) * 8 + x) * nrg + (q & (nrg - 1u));
+}
+
 struct move_list {
     uint32_t nsteps;
     uint32_t step_end[UP_MAX_STEPS];
@@ -562,7 +575,10 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8) {
     __shared__ uint32_t mvl[CU_MAX_MOVES];  // the move list, staged once (a global load in P2 would drain the prefetch)
     const uint32_t su = threadIdx.x >> 2, quad = threadIdx.x & 3;  // owner mapping of part P3
     // INV: thread owns sub-unit su (8 words) x row quad; forward load: word wl = it >> 2 of pass i
-    auto gptr = [&](uint32_t t) { return D + (uint64_t)(t >> 3) * 2048 * ROWS + (t & 7) * CT_ROWS; };
+    auto gptr = [&](uint32_t v) {
+        const uint32_t t = xcd_slice_order(v, 8, ntiles8);
+        return D + (uint64_t)(t >> 3) * 2048 * ROWS + (t & 7) * CT_ROWS;
+    };
     uint32_t t = blockIdx.x;
     if (t >= ntiles8) return;
     for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += CT_THREADS) mvl[i] = mv.list[i];
@@ -770,11 +786,12 @@ __global__ void __launch_bounds__(CT_THREADS)
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
     const uint32_t nrg = 32u >> t.lrq;  // row groups
     const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);  // == 8192 (make_taylor)
-    uint32_t b = blockIdx.x;
-    if (b >= ntiles) return;
-    cu_regs nx = ty_fetch_tile(Din, t, ncoltiles, b);
+    uint32_t vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    cu_regs nx = ty_fetch_tile(Din, t, ncoltiles, xcd_slice_order(vb, nrg, ntiles));
 #pragma unroll 1
-    for (; b < ntiles; b += gridDim.x) {
+    for (; vb < ntiles; vb += gridDim.x) {
+        const uint32_t b = xcd_slice_order(vb, nrg, ntiles);
         const uint32_t rg = b % nrg, g = (b / nrg) & ((1u << t.lg) - 1u), bc = (b / nrg) >> t.lg;
         const uint32_t cb = bc % ncoltiles;
         const uint32_t grp = bc / ncoltiles;
@@ -788,7 +805,7 @@ __global__ void __launch_bounds__(CT_THREADS)
             lds[i + 7 * CT_THREADS] = nx.h;
         }
         __syncthreads();
-        nx = ty_fetch_tile(Din, t, ncoltiles, b + gridDim.x < ntiles ? b + gridDim.x : b);
+        nx = ty_fetch_tile(Din, t, ncoltiles, xcd_slice_order(vb + gridDim.x < ntiles ? vb + gridDim.x : vb, nrg, ntiles));
         for (uint32_t q = 0; q < t.nph; q++) {
             const uint32_t i = inverse ? t.nph - 1 - q : q;
             const uint32_t lchunk = t.lchunk[i], lpw = t.lpw[i];
@@ -828,7 +845,8 @@ struct wu_phases {
 };
 // tile = all 2^nub units x one word offset x 2^lq row quads, lq = 13 - nub (4 quads = 64 B per unit at nub = 11, the
 // whole 512-B granule at nub = 8): always 8192 u4 = 128 KiB, [unit][quad]
-__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t lq, uint32_t tile) {
+__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t lq, uint32_t vtile) {
+    const uint32_t tile = xcd_slice_order(vtile, 32u >> lq, 2048u << (5 - lq));
     const uint32_t o = tile >> (5 - lq), rg = tile & ((32u >> lq) - 1u);
     const uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
     auto ld = [&](uint32_t it) { return ld_u4(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & ((1u << lq) - 1u))); };
@@ -879,7 +897,8 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             __syncthreads();
         }
         {
-            const uint32_t o = t >> (5 - lq), rg = t & ((32u >> lq) - 1u);
+            const uint32_t tt = xcd_slice_order(t, 32u >> lq, ntiles);
+            const uint32_t o = tt >> (5 - lq), rg = tt & ((32u >> lq) - 1u);
             uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
             for (uint32_t it = threadIdx.x; it < 8192; it += CT_THREADS)
                 *(u4 *)(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & qm)) = lds[it];

@@ -49,6 +49,25 @@ __global__ void __launch_bounds__(512) k_copy(uint32_t *Z, pat p, uint32_t ntile
     if (!STORE && v[0] == 0x12345678u) Z[0] = v[1];
 }
 
+// 64-B pieces (4 lanes x 16 B) at a stride of 512 B, the eight pieces of a 512-B word read by eight different workgroups:
+// the access pattern of k_conv_unit / k_conv_tile (16-row tiles). Reads all 512 MiB once; for calibrating FETCH_SIZE.
+// MAP 0: piece = blockIdx % 8 (so XCD k reads piece k of every word); MAP 1: the eight pieces of a chunk of words on eight
+// workgroups of ONE XCD (blockIdx = xcd + 8 * (piece + 8 * s)). WR: also write the piece back.
+template <int MAP, int WR>
+__global__ void __launch_bounds__(1024) k_piece64(uint32_t *Z, uint32_t *out) {
+    const uint32_t quad = threadIdx.x & 3;
+    const uint32_t b = blockIdx.x;
+    const uint32_t tq = MAP ? (b >> 3) & 7 : b & 7;
+    const uint32_t chunk = MAP ? ((b >> 6) << 3) | (b & 7) : b >> 3;
+    const uint32_t word = chunk * 256 + (threadIdx.x >> 2);
+    uint4 *p = (uint4 *)(Z + (uint64_t)word * 128 + tq * 16 + quad * 4);
+    uint4 v = *p;
+    if (WR) {
+        v.x += 1;
+        *p = v;
+    } else if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345678u) out[0] = v.x;
+}
+
 int main() {
     uint32_t *Z;
     const size_t bytes = 512ull << 20;
@@ -88,6 +107,22 @@ int main() {
                 printf("%s %s grid %4u  %.3f ms  %.2f TB/s\n", store ? "read+write" : "read only ", n.name, grid, best,
                        (store ? 2.0 : 1.0) * bytes / best * 1e-9);
             }
+        }
+    for (int var = 0; var < 4; var++)
+        for (int rep = 0; rep < 3; rep++) {
+            CK(hipEventRecord(e0));
+            const dim3 g(8 * 4096), t(1024);
+            switch (var) {
+                case 0: hipLaunchKernelGGL((k_piece64<0, 0>), g, t, 0, 0, Z, Z); break;
+                case 1: hipLaunchKernelGGL((k_piece64<1, 0>), g, t, 0, 0, Z, Z); break;
+                case 2: hipLaunchKernelGGL((k_piece64<0, 1>), g, t, 0, 0, Z, Z); break;
+                default: hipLaunchKernelGGL((k_piece64<1, 1>), g, t, 0, 0, Z, Z); break;
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%s 64-B pieces at stride 512 B, pieces of a word on %s: %.3f ms  %.2f TB/s\n", var & 2 ? "read+write" : "read only ",
+                   var & 1 ? "one XCD   " : "eight XCDs", ms, (var & 2 ? 2.0 : 1.0) * bytes / ms * 1e-9);
         }
     CK(hipGetLastError());
     return 0;
