@@ -32,6 +32,7 @@ QC_BYTES_PER_OT = 48.0  # 32 B read (rT) + 16 B write pe
 # AES stage ceiling: 160 T-table lookups (ds_read_b32) per block; a wave64 ds_read_b32 occupies the CU's LDS for
 # 2 cycles (MI355X_MICROARCH.md, LDS table) -> 256 CUs x 2.4 GHz / 2 x 64 lanes / 160 lookups
 AES_PEAK_PER_S = 256 * 2.4e9 / 2 * 64 / 160
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2  # wave-instructions/s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles
 GGM_KERNELS = ("k_roots", "k_ggm_level", "k_ggm_leaf", "k_sender_treegrp", "k_recv_init", "k_recv_fix", "k_recv_last")
 QC_KERNELS = ("k_clear_lsb", "k_qc_load", "k_conv_fwd", "k_conv_fwd_tile", "k_fft_top", "k_fft_mid", "k_fft_low_mul",
               "k_ifft_mid", "k_ifft_top", "k_conv_inv_tile", "k_conv_inv", "k_qc_store", "k_qc_final")
@@ -178,6 +179,66 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
 
 
 VALU_BITOP3_PEAK = 8.0e11  # measured: tools/micro/valu_rate.hip, profiles/r1_valu_issue_rates.txt
+
+
+def alsz_bench(fa, torch, device, log2n, reps):
+    """ALSZ13 OT extension with device-resident contexts: receiver (2 PRG blocks per row and 128 OTs, one
+    hash per OT) then sender (1 PRG block, two hashes), u rows handed over device-to-device, results left in HBM. Per
+    extension: 3 AES blocks on each side; HBM bytes: receiver 16 (u) + 16 (message) + 1/8 (choice), sender 16 + 32."""
+    from flute_amd import ot_ext
+    count = 1 << log2n
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, 2 ** 64, (128, 2, 2), dtype=np.uint64)
+    bc = rng.integers(0, 256, 16, dtype=np.uint8)
+    bcb = np.unpackbits(bc, bitorder="little")
+    chosen = np.ascontiguousarray(pairs[np.arange(128), bcb])
+    R = ot_ext.Receiver(pairs, device=device, max_count=count)
+    S = ot_ext.Sender(chosen, bc.tobytes(), device=device, max_count=count)
+    ch = torch.from_numpy(rng.integers(0, 256, count // 8, dtype=np.uint8)).cuda(device)
+    torch.cuda.synchronize()
+
+    def once():
+        R.receive_random(None, count, to_host=False, choices_dev=ch.data_ptr())
+        R.ctx.sync()
+        t1 = time.perf_counter()
+        S.send_random(None, count, to_host=False, u_dev=R.ctx.u_dev)
+        S.ctx.sync()
+        return t1
+    once()
+    tr = ts = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        t1 = once()
+        t2 = time.perf_counter()
+        tr += t1 - t0
+        ts += t2 - t1
+    # spot check on the last run: message of OT i on the receiver = the sender's message pair entry chosen by bit i
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    k = 4096
+    rm = np.empty((k, 2), dtype=np.uint64)
+    sm = np.empty((k, 2, 2), dtype=np.uint64)
+    hip.hipMemcpy(rm.ctypes.data_as(C.c_void_p), C.c_void_p(R.ctx.msgs_dev), C.c_size_t(rm.nbytes), 2)
+    hip.hipMemcpy(sm.ctypes.data_as(C.c_void_p), C.c_void_p(S.ctx.msgs_dev), C.c_size_t(sm.nbytes), 2)
+    bits = np.unpackbits(ch[:k // 8].cpu().numpy(), bitorder="little")
+    ok = bool(np.array_equal(rm, sm[np.arange(k), bits]))
+    R.ctx.close()
+    S.ctx.close()
+    ms_r, ms_s = tr / reps * 1e3, ts / reps * 1e3
+    aes_r = 3.0 * count / (ms_r * 1e-3)
+    aes_s = 3.0 * count / (ms_s * 1e-3)
+    return {
+        "metric": "ALSZ13 OT extensions/s, receiver then sender on one GPU, device-resident (zappot ot_ext, n = 2^%d)" % log2n,
+        "value": count / ((ms_r + ms_s) * 1e-3), "unit": "OTs/s", "count": count,
+        "receiver_ms": ms_r, "sender_ms": ms_s, "receiver_equals_sender_choice": ok,
+        "receiver": {"aes_blocks_per_s": aes_r, "frac_of_lds_lookup_peak": aes_r / AES_PEAK_PER_S,
+                     "hbm_bytes_per_ot": 32.125, "hbm_gb_per_s": 32.125 * count / (ms_r * 1e-3) / 1e9},
+        "sender": {"aes_blocks_per_s": aes_s, "frac_of_lds_lookup_peak": aes_s / AES_PEAK_PER_S,
+                   "hbm_bytes_per_ot": 48.0, "hbm_gb_per_s": 48.0 * count / (ms_s * 1e-3) / 1e9},
+        "bound": "lds (AES T-table lookups: 3 blocks per extension per side) + the 128 x 128 bit transposes through LDS",
+        "note": "wall time of one call per side incl. 256 / 128 host key schedules and their upload; one-shot "
+                "sot_alsz_send / sot_alsz_receive add device allocation and PCIe copies of the u rows and messages",
+    }
 
 
 def load_pmc():
@@ -332,6 +393,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsals on a 1-GPU box)")
     ap.add_argument("--lut-log2b", type=int, default=16, help="FLUTE setup section (0 = skip)")
+    ap.add_argument("--alsz-log2n", type=int, default=24, help="ALSZ13 OT-extension section (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--mode", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = ONE expansion sharded over the ranks (default), weak = one instance per rank")
@@ -439,7 +501,7 @@ def main():
             "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, n=2^%d random OTs per direction, "
                                    "sender+receiver expansion + MT bits on each GPU" % args.log2n,
                        "P": conf.P, "trees": conf.parts, "depth": conf.depth, "threads_T": args.threads,
-                       "sharding": ("independent instances per rank; MT store (a | b | c, 3n bits per rank) all-gathered over "
+                       "sharding": "single GPU" if world == 1 else ("independent instances per rank; MT store (a | b | c, 3n bits per rank) all-gathered over "
                                     "RCCL every step" if gather["on"] else "independent instances per rank (no collective)")},
         }
         if gather["note"]:
@@ -482,6 +544,20 @@ def main():
             if pmc:
                 out["roofline"]["traffic"] = pmc.get("dominant_traffic_bytes_per_launch")
                 out["roofline"]["traffic_note"] = pmc.get("note")
+                if pmc.get("qc_stage_traffic_bytes_per_direction") and n == 1 << 24:
+                    # the whole QC-encode stage of one direction, summed over its launches from the same committed passes
+                    # (FETCH_SIZE corrected per access pattern, tools/prof_summary.py) against the 48 B/OT it has to move
+                    st = pmc["qc_stage_traffic_bytes_per_direction"]
+                    out["roofline"]["stage_traffic_bytes"] = st
+                    out["roofline"]["stage_algorithmic_bytes"] = QC_BYTES_PER_OT * n
+                    out["roofline"]["stage_traffic_ratio"] = st / (QC_BYTES_PER_OT * n)
+                    out["roofline"]["stage_traffic_gb_per_s"] = st / ((qc_ms / 2.0) * 1e-3) / 1e9
+                if pmc.get("ggm_valu_insts_per_s") and n == 1 << 24:
+                    # GGM stage against the hardware's own peaks (counters of the committed pass): VALU issue = one wave
+                    # instruction per 2 cycles and SIMD; LDS busy = 2 cycles of the CU's LDS pipe per wave64 ds_read_b32
+                    stages["ggm_expand"]["valu_issue_frac_of_peak"] = pmc["ggm_valu_insts_per_s"] / VALU_ISSUE_PEAK
+                    stages["ggm_expand"]["lds_busy_frac"] = pmc["ggm_lds_insts_per_s"] * 2.0 / (256 * 2.4e9)
+                    stages["ggm_expand"]["counters_source"] = pmc.get("source")
                 if pmc.get("valu_insts_per_launch") and n == 1 << 24:
                     # what actually bounds the dominant kernel: VALU issue. Wave-instructions per
                     # launch (PMC SQ_INSTS_VALU, same committed pass) / measured launch time, against the measured
@@ -501,6 +577,11 @@ def main():
             except Exception as e:  # a secondary section: never takes the headline line down
                 out["lut_setup"] = {"value": None, "note": "failed: %r" % (e,)}
         out["aes128"] = aes128_workloads(fa, n, ms_per_step, out.get("lut_setup"))
+        if args.alsz_log2n and world == 1:
+            try:
+                out["alsz"] = alsz_bench(fa, torch, local_rank, args.alsz_log2n, 5)
+            except Exception as e:
+                out["alsz"] = {"value": None, "note": "failed: %r" % (e,)}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_log2n, args.threads)

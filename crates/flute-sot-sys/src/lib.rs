@@ -61,6 +61,10 @@ pub struct SotCtx {
 pub struct SotAndCirc {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct SotAlszCtx {
+    _private: [u8; 0],
+}
 
 #[link(name = "flute_sot")]
 extern "C" {
@@ -103,6 +107,13 @@ extern "C" {
     pub fn sot_mt_remaining(ctx: *const SotCtx) -> u64;
     pub fn sot_alsz_receive(device: c_int, base_ots: *const c_void, choice_bytes: *const u8, count: u64, u_rows_out: *mut u8, msgs_out: *mut c_void) -> c_int;
     pub fn sot_alsz_send(device: c_int, base_ots: *const c_void, base_choices: *const c_void, u_rows: *const u8, count: u64, msgs_out: *mut c_void) -> c_int;
+    pub fn sot_alsz_ctx_create(device: c_int, max_count: u64, out: *mut *mut SotAlszCtx) -> c_int;
+    pub fn sot_alsz_ctx_destroy(actx: *mut SotAlszCtx);
+    pub fn sot_alsz_ctx_receive(actx: *mut SotAlszCtx, base_ots: *const c_void, choice_bytes: *const u8, choices_on_device: c_int, count: u64, u_rows_out: *mut u8, msgs_out: *mut c_void) -> c_int;
+    pub fn sot_alsz_ctx_send(actx: *mut SotAlszCtx, base_ots: *const c_void, base_choices: *const c_void, u_rows: *const u8, u_dev: *const c_void, count: u64, msgs_out: *mut c_void) -> c_int;
+    pub fn sot_alsz_ctx_msgs_dev(actx: *mut SotAlszCtx) -> *mut c_void;
+    pub fn sot_alsz_ctx_u_dev(actx: *mut SotAlszCtx) -> *mut c_void;
+    pub fn sot_alsz_ctx_sync(actx: *mut SotAlszCtx) -> c_int;
     pub fn sot_alsz_receive_noalloc(device: c_int, base_ots: *const c_void, choice_bytes: *const u8, count: u64, u_rows_out: *mut u8, msgs_out: *mut c_void) -> c_int;
     pub fn sot_alsz_noalloc_max_count() -> u64;
     pub fn sot_random_silent_send(ctx: *mut SotCtx, base_ots: *const c_void, delta: *const c_void, seed: *const c_void, num_threads: u64, tg_sums_out: *mut c_void, tg_last_out: *mut c_void, msgs_out: *mut c_void) -> c_int;

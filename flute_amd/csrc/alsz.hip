@@ -76,6 +76,160 @@ __global__ void __launch_bounds__(AZ_THREADS)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-resident OT-extension context = one zappot::ot_ext::Sender or Receiver (ot_ext/mod.rs:28-46, :144-154) for up
+// to max_count extensions per call: every device buffer is allocated once, the calls only copy what the caller asks for.
+struct sot_alsz_ctx {
+    int device;
+    uint64_t max_count, max_nj;
+    hipStream_t stream;
+    uint32_t *d_rks;  // [256][44]
+    blk_t *d_ch;      // [max_nj] padded choice Blocks
+    blk_t *d_U;       // [128][nj] Blocks (row stride = nj of the last call)
+    blk_t *d_out;     // [max_count] (receiver) / [2 max_count] (sender)
+    uint8_t *d_bc;    // [128]
+    uint32_t *h_rks;  // pinned staging of the expanded keys
+    uint64_t last_count, last_nj;
+    std::mutex mu;
+};
+
+static void alsz_free(sot_alsz_ctx *a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    void *ptrs[] = {a->d_rks, a->d_ch, a->d_U, a->d_out, a->d_bc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (a->h_rks) (void)hipHostFree(a->h_rks);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+extern "C" int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx **out) {
+    if (!out || max_count == 0) return SOT_EINVAL;
+    *out = nullptr;
+    SOT_HIP(hipSetDevice(device));
+    sot_alsz_ctx *a = new sot_alsz_ctx();
+    a->device = device;
+    a->max_count = max_count;
+    a->max_nj = (max_count + 127) / 128;
+    a->last_count = a->last_nj = 0;
+    a->stream = nullptr;
+    a->d_rks = nullptr, a->d_ch = nullptr, a->d_U = nullptr, a->d_out = nullptr, a->d_bc = nullptr, a->h_rks = nullptr;
+    const bool ok = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipMalloc((void **)&a->d_rks, 256 * 44 * 4) == hipSuccess &&
+                    hipMalloc((void **)&a->d_ch, a->max_nj * 16) == hipSuccess &&
+                    hipMalloc((void **)&a->d_U, (size_t)128 * a->max_nj * 16) == hipSuccess &&
+                    hipMalloc((void **)&a->d_out, (size_t)a->max_nj * 128 * 32) == hipSuccess &&
+                    hipMalloc((void **)&a->d_bc, 128) == hipSuccess &&
+                    hipHostMalloc((void **)&a->h_rks, 256 * 44 * 4 + 128, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        alsz_free(a);
+        sot_set_error("alsz: device allocation failed for %llu OT extensions per call", (unsigned long long)max_count);
+        return SOT_ENOMEM;
+    }
+    *out = a;
+    return SOT_OK;
+}
+extern "C" void sot_alsz_ctx_destroy(sot_alsz_ctx *a) { alsz_free(a); }
+extern "C" void *sot_alsz_ctx_msgs_dev(sot_alsz_ctx *a) { return a ? a->d_out : nullptr; }
+extern "C" void *sot_alsz_ctx_u_dev(sot_alsz_ctx *a) { return a ? a->d_U : nullptr; }
+extern "C" int sot_alsz_ctx_sync(sot_alsz_ctx *a) {
+    if (!a) return SOT_EINVAL;
+    std::lock_guard<std::mutex> lk(a->mu);
+    SOT_HIP(hipSetDevice(a->device));
+    SOT_HIP(hipStreamSynchronize(a->stream));
+    return SOT_OK;
+}
+
+static int alsz_check(const sot_alsz_ctx *a, uint64_t count) {
+    if (count == 0 || count % 8) {
+        sot_set_error("alsz: the number of OT extensions must be a positive multiple of 8 (ot_ext/mod.rs:58-62)");
+        return SOT_EINVAL;
+    }
+    if (count > a->max_count) {
+        sot_set_error("alsz: %llu OT extensions requested from a context created for %llu", (unsigned long long)count,
+                      (unsigned long long)a->max_count);
+        return SOT_EINVAL;
+    }
+    return SOT_OK;
+}
+// expands the nkeys base-OT seeds into the pinned staging buffer and starts their upload
+static int alsz_keys(sot_alsz_ctx *a, const void *base_ots, uint32_t nkeys) {
+    SOT_HIP(hipStreamSynchronize(a->stream));  // the staging buffer may still feed the previous call's copy
+    for (uint32_t k = 0; k < nkeys; k++) {
+        aes_rk rk;
+        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
+        memcpy(a->h_rks + k * 44, rk.w, 176);
+    }
+    SOT_HIP(hipMemcpyAsync(a->d_rks, a->h_rks, (size_t)nkeys * 176, hipMemcpyHostToDevice, a->stream));
+    return SOT_OK;
+}
+static inline unsigned alsz_grid(uint64_t nj) {
+    uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
+    return (unsigned)(g > 512 ? 512 : g);
+}
+
+// Receiver::receive (ot_ext/mod.rs:156-237). choice_bytes: count / 8 bytes, host memory or (choices_on_device != 0)
+// device memory. u_rows_out (the message for the sender: [128][count / 8] bytes) and msgs_out ([count] Blocks) are host
+// buffers or NULL: with NULL the data stays on the device (sot_alsz_ctx_u_dev: [128][ceil(count / 128)] Blocks,
+// sot_alsz_ctx_msgs_dev) and the call returns without waiting for the kernel (sot_alsz_ctx_sync).
+extern "C" int sot_alsz_ctx_receive(sot_alsz_ctx *a, const void *base_ots, const uint8_t *choice_bytes, int choices_on_device,
+                                    uint64_t count, uint8_t *u_rows_out, void *msgs_out) {
+    if (!a || !base_ots || !choice_bytes) return SOT_EINVAL;
+    SOT_TRY(alsz_check(a, count));
+    std::lock_guard<std::mutex> lk(a->mu);
+    SOT_HIP(hipSetDevice(a->device));
+    const uint64_t cols = count / 8, nj = (count + 127) / 128;
+    SOT_TRY(alsz_keys(a, base_ots, 256));
+    if (cols % 16) SOT_HIP(hipMemsetAsync((uint8_t *)a->d_ch + (cols & ~15ull), 0, 16, a->stream));  // pad the last Block
+    SOT_HIP(hipMemcpyAsync(a->d_ch, choice_bytes, cols, choices_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           a->stream));
+    hipLaunchKernelGGL(k_alsz<false>, dim3(alsz_grid(nj)), dim3(AZ_THREADS), 0, a->stream, a->d_rks, a->d_ch,
+                       make_uint4(0, 0, 0, 0), (const uint8_t *)nullptr, a->d_U, nj, count, a->d_out);
+    SOT_HIP(hipGetLastError());
+    a->last_count = count, a->last_nj = nj;
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, a->d_out, count * 16, hipMemcpyDeviceToHost, a->stream));
+    // row r of the device matrix is nj Blocks wide, the caller's is count / 8 bytes
+    if (u_rows_out) SOT_HIP(hipMemcpy2DAsync(u_rows_out, cols, a->d_U, nj * 16, cols, 128, hipMemcpyDeviceToHost, a->stream));
+    if (msgs_out || u_rows_out) SOT_HIP(hipStreamSynchronize(a->stream));
+    return SOT_OK;
+}
+
+// Sender::send (ot_ext/mod.rs:48-142). The receiver's message comes from host memory (u_rows: [128][count / 8] bytes) or,
+// with u_rows == NULL, from device memory (u_dev: [128][ceil(count / 128)] Blocks, e.g. another context's
+// sot_alsz_ctx_u_dev on the same GPU). msgs_out: [count][2] Blocks on the host, or NULL (sot_alsz_ctx_msgs_dev).
+extern "C" int sot_alsz_ctx_send(sot_alsz_ctx *a, const void *base_ots, const void *base_choices, const uint8_t *u_rows,
+                                 const void *u_dev, uint64_t count, void *msgs_out) {
+    if (!a || !base_ots || !base_choices || (!u_rows && !u_dev)) return SOT_EINVAL;
+    SOT_TRY(alsz_check(a, count));
+    std::lock_guard<std::mutex> lk(a->mu);
+    SOT_HIP(hipSetDevice(a->device));
+    const uint64_t cols = count / 8, nj = (count + 127) / 128;
+    SOT_TRY(alsz_keys(a, base_ots, 128));
+    blk_t delta;
+    memcpy(&delta, base_choices, 16);
+    uint8_t *bc = (uint8_t *)(a->h_rks + 256 * 44);
+    for (int i = 0; i < 128; i++) bc[i] = (((const uint8_t *)base_choices)[i >> 3] >> (i & 7)) & 1;
+    SOT_HIP(hipMemcpyAsync(a->d_bc, bc, 128, hipMemcpyHostToDevice, a->stream));
+    const blk_t *U = (const blk_t *)u_dev;
+    if (u_rows) {
+        if (cols % 16) SOT_HIP(hipMemsetAsync(a->d_U, 0, (size_t)128 * nj * 16, a->stream));  // rows end inside a Block
+        SOT_HIP(hipMemcpy2DAsync(a->d_U, nj * 16, u_rows, cols, cols, 128, hipMemcpyHostToDevice, a->stream));
+        U = a->d_U;
+    }
+    hipLaunchKernelGGL(k_alsz<true>, dim3(alsz_grid(nj)), dim3(AZ_THREADS), 0, a->stream, a->d_rks, (const blk_t *)nullptr,
+                       delta, a->d_bc, (blk_t *)U, nj, count, a->d_out);
+    SOT_HIP(hipGetLastError());
+    a->last_count = count, a->last_nj = nj;
+    if (msgs_out) {
+        SOT_HIP(hipMemcpyAsync(msgs_out, a->d_out, count * 32, hipMemcpyDeviceToHost, a->stream));
+        SOT_HIP(hipStreamSynchronize(a->stream));
+    }
+    return SOT_OK;
+}
+
+// one-shot forms: a context for exactly this call
 static int alsz_run(bool sender, int device, const void *base_ots, const uint8_t *choice_bytes, const void *base_choices,
                     uint8_t *u_rows, uint64_t count, void *msgs_out) {
     if (!base_ots || !u_rows || !msgs_out || (sender ? !base_choices : !choice_bytes)) return SOT_EINVAL;
@@ -83,63 +237,11 @@ static int alsz_run(bool sender, int device, const void *base_ots, const uint8_t
         sot_set_error("alsz: the number of OT extensions must be a positive multiple of 8 (ot_ext/mod.rs:58-62)");
         return SOT_EINVAL;
     }
-    SOT_HIP(hipSetDevice(device));
-    const uint64_t cols = count / 8, nj = (count + 127) / 128, nkeys = sender ? 128 : 256;
-    std::vector<uint32_t> rks(nkeys * 44);
-    for (uint64_t k = 0; k < nkeys; k++) {
-        aes_rk rk;
-        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
-        memcpy(&rks[k * 44], rk.w, 176);
-    }
-    std::vector<uint8_t> bc(128, 0);
-    blk_t delta = make_uint4(0, 0, 0, 0);
-    if (sender) {
-        memcpy(&delta, base_choices, 16);
-        for (int i = 0; i < 128; i++) bc[i] = (((const uint8_t *)base_choices)[i >> 3] >> (i & 7)) & 1;
-    }
-    // padded images: choices as nj Blocks, U as [128][nj] Blocks
-    std::vector<uint8_t> pad(nj * 16, 0), ubuf((size_t)128 * nj * 16, 0);
-    if (!sender) memcpy(pad.data(), choice_bytes, cols);
-    if (sender)
-        for (int r = 0; r < 128; r++) memcpy(&ubuf[(size_t)r * nj * 16], u_rows + (size_t)r * cols, cols);
-    uint32_t *d_rks = nullptr;
-    blk_t *d_ch = nullptr, *d_U = nullptr, *d_out = nullptr;
-    uint8_t *d_bc = nullptr;
-    const uint64_t out_bytes = count * (sender ? 32 : 16);
-    int rc = SOT_OK;
-    if (hipMalloc((void **)&d_rks, rks.size() * 4) != hipSuccess || hipMalloc((void **)&d_ch, nj * 16) != hipSuccess ||
-        hipMalloc((void **)&d_U, (size_t)128 * nj * 16) != hipSuccess || hipMalloc((void **)&d_out, out_bytes) != hipSuccess ||
-        hipMalloc((void **)&d_bc, 128) != hipSuccess)
-        rc = SOT_ENOMEM;
-    if (rc == SOT_OK) {
-        (void)hipMemcpy(d_rks, rks.data(), rks.size() * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_ch, pad.data(), nj * 16, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_bc, bc.data(), 128, hipMemcpyHostToDevice);
-        if (sender) (void)hipMemcpy(d_U, ubuf.data(), ubuf.size(), hipMemcpyHostToDevice);
-        uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
-        if (g > 512) g = 512;
-        if (sender)
-            hipLaunchKernelGGL(k_alsz<true>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, delta, d_bc, d_U, nj,
-                               count, d_out);
-        else
-            hipLaunchKernelGGL(k_alsz<false>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, delta, d_bc, d_U, nj,
-                               count, d_out);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(msgs_out, d_out, out_bytes, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && !sender) {
-            e = hipMemcpy(ubuf.data(), d_U, ubuf.size(), hipMemcpyDeviceToHost);
-            for (int r = 0; r < 128 && e == hipSuccess; r++) memcpy(u_rows + (size_t)r * cols, &ubuf[(size_t)r * nj * 16], cols);
-        }
-        if (e != hipSuccess) {
-            sot_set_error("alsz: %s", hipGetErrorString(e));
-            rc = SOT_EDEVICE;
-        }
-    } else {
-        sot_set_error("alsz: device allocation failed");
-    }
-    void *ptrs[] = {d_rks, d_ch, d_U, d_out, d_bc};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    sot_alsz_ctx *a = nullptr;
+    SOT_TRY(sot_alsz_ctx_create(device, count, &a));
+    const int rc = sender ? sot_alsz_ctx_send(a, base_ots, base_choices, u_rows, nullptr, count, msgs_out)
+                          : sot_alsz_ctx_receive(a, base_ots, choice_bytes, 0, count, u_rows, msgs_out);
+    alsz_free(a);
     return rc;
 }
 

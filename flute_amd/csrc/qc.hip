@@ -1796,8 +1796,14 @@ __global__ void __launch_bounds__(64 * NVW)
     __shared__ uint32_t lds[32 * NVW * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t rh = blockIdx.x & 1;
-    const uint32_t o = blockIdx.x >> 1;
+    // the two row halves of a tile read the same 14 KiB of masks per value word: they go to workgroups b and b + 8, which
+    // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
+    // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
+    uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
+    if (gridDim.x % 16 == 0) {
+        rh = (blockIdx.x >> 3) & 1;
+        o = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
+    }
     const uint32_t base_w = tile_base(d, o);
     const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
     // first mask lines of this wave's value word (see mask_prefetch); issued before the tile's own loads, so they

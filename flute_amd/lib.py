@@ -38,7 +38,8 @@ EXPORTS = [
     "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
     "sot_and_circ_set_inputs", "sot_and_circ_layer_msg", "sot_and_circ_layer_eval", "sot_and_circ_layer_eval_peer",
     "sot_and_circ_values", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
-    "sot_alsz_noalloc_max_count", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves",
+    "sot_alsz_noalloc_max_count", "sot_alsz_ctx_create", "sot_alsz_ctx_destroy", "sot_alsz_ctx_receive",
+    "sot_alsz_ctx_send", "sot_alsz_ctx_msgs_dev", "sot_alsz_ctx_u_dev", "sot_alsz_ctx_sync", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves",
     "sot_shard_unpack_leaves", "sot_shard_local_leaves", "sot_shard_qc_encode", "sot_shard_unpack_encoded",
 ]
 
@@ -116,6 +117,16 @@ def load_library():
     L.sot_alsz_send.argtypes = [i32, P, P, P, u64, P]
     L.sot_alsz_receive_noalloc.argtypes = [i32, P, P, u64, P, P]
     L.sot_alsz_noalloc_max_count.restype = u64
+    L.sot_alsz_ctx_create.argtypes = [i32, u64, P]
+    L.sot_alsz_ctx_destroy.argtypes = [P]
+    L.sot_alsz_ctx_destroy.restype = None
+    L.sot_alsz_ctx_receive.argtypes = [P, P, P, i32, u64, P, P]
+    L.sot_alsz_ctx_send.argtypes = [P, P, P, P, P, u64, P]
+    L.sot_alsz_ctx_msgs_dev.argtypes = [P]
+    L.sot_alsz_ctx_msgs_dev.restype = P
+    L.sot_alsz_ctx_u_dev.argtypes = [P]
+    L.sot_alsz_ctx_u_dev.restype = P
+    L.sot_alsz_ctx_sync.argtypes = [P]
     L.sot_ctx_create_sharded.argtypes = [u64, u64, i32, C.c_uint32, C.c_uint32, i32, C.POINTER(P)]
     L.sot_shard_info_get.argtypes = [P, C.POINTER(ShardInfo)]
     L.sot_shard_pack_leaves.argtypes = [P, P]

@@ -209,6 +209,28 @@ int sot_alsz_receive(int device, const void *base_ots, const uint8_t *choice_byt
 int sot_alsz_send(int device, const void *base_ots, const void *base_choices, const uint8_t *u_rows, uint64_t count,
                   void *msgs_out);
 
+/* Device-resident OT-extension context: one zappot::ot_ext::Sender or Receiver instance (ot_ext/mod.rs:28-46, :144-154)
+ * whose device buffers (expanded keys, choices, the 128 x count u-row matrix, the hashed messages) are allocated once,
+ * for up to max_count extensions per call. The one-shot sot_alsz_receive / sot_alsz_send above are this context created
+ * and destroyed around a single call. Calls on one context are serialised by a lock; they run on the context's stream. */
+typedef struct sot_alsz_ctx sot_alsz_ctx;
+int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx **out);
+void sot_alsz_ctx_destroy(sot_alsz_ctx *actx);
+/* Receiver::receive_random, local part (:193-235). choice_bytes: count/8 bytes in host memory, or in device memory when
+ * choices_on_device != 0. u_rows_out ([128][count/8] bytes) and msgs_out (count Blocks) are host buffers or NULL: with
+ * both NULL nothing leaves the GPU and the call returns without waiting (sot_alsz_ctx_sync). */
+int sot_alsz_ctx_receive(sot_alsz_ctx *actx, const void *base_ots, const uint8_t *choice_bytes, int choices_on_device,
+                         uint64_t count, uint8_t *u_rows_out, void *msgs_out);
+/* Sender::send_random, local part (:91-140). The receiver's u rows come from host memory (u_rows: [128][count/8] bytes)
+ * or, with u_rows == NULL, from device memory (u_dev: [128][ceil(count/128)] Blocks, the layout of sot_alsz_ctx_u_dev of
+ * a receiver context on the same GPU: in-process two-party runs). msgs_out: count x [Block; 2] on the host, or NULL. */
+int sot_alsz_ctx_send(sot_alsz_ctx *actx, const void *base_ots, const void *base_choices, const uint8_t *u_rows,
+                      const void *u_dev, uint64_t count, void *msgs_out);
+/* device pointers to the last call's results: messages (count Blocks / count x [Block; 2]) and the u-row matrix */
+void *sot_alsz_ctx_msgs_dev(sot_alsz_ctx *actx);
+void *sot_alsz_ctx_u_dev(sot_alsz_ctx *actx);
+int sot_alsz_ctx_sync(sot_alsz_ctx *actx);
+
 /* The one entry point that allocates nothing. NO counterpart in the reference: it exists for callers that cannot call
  * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same arguments,
  * computation and results as sot_alsz_receive, but the device buffers (expanded keys, padded choices, u-row matrix,

@@ -39,3 +39,57 @@ def test_alsz_full_size_property():
     assert not np.array_equal(recv[:1000], sent[:1000, 0]) or bits[:1000].sum() == 0
     with pytest.raises(Exception):
         ot_ext.Receiver(pairs).receive_random(b"\0" * 2, 12)
+
+
+def test_alsz_context_reused_across_calls_matches_oracle():
+    """device-resident contexts (sot_alsz_ctx_*): three calls in a row on the same pair of contexts, sizes going down and
+    up again (stale buffer contents must not leak into a smaller call), each equal to the oracle"""
+    from flute_amd import ot_ext
+    from oracle import alsz_oracle as az
+    rng = np.random.default_rng(11)
+    pairs, chosen, bc = az.fake_base(rng)
+    R = ot_ext.Receiver(pairs, max_count=70000)
+    S = ot_ext.Sender(chosen, bc.tobytes(), max_count=70000)
+    for count in (65536, 1000, 8, 69992):
+        bits = rng.integers(0, 2, count, dtype=np.uint8)
+        cb = np.packbits(bits, bitorder="little").tobytes()
+        u, recv = R.receive_random(cb, count)
+        ou, orecv = az.receive_random(pairs, cb, count)
+        assert np.array_equal(u, ou) and np.array_equal(recv, orecv), count
+        sent = S.send_random(u, count)
+        assert np.array_equal(sent, az.send_random(chosen, bc.tobytes(), ou, count)), count
+    with pytest.raises(Exception):
+        R.receive_random(b"\0" * 10000, 70008)  # beyond max_count
+
+
+def test_alsz_device_resident_handoff():
+    """receiver results left in HBM, the sender reads the u rows device-to-device (in-process two-party run), and the
+    downloaded device buffers equal the host-buffer path"""
+    import torch
+    from flute_amd import ot_ext
+    from oracle import alsz_oracle as az
+    count = 100008
+    rng = np.random.default_rng(12)
+    pairs, chosen, bc = az.fake_base(rng)
+    bits = rng.integers(0, 2, count, dtype=np.uint8)
+    cbn = np.packbits(bits, bitorder="little")
+    R = ot_ext.Receiver(pairs, max_count=count)
+    S = ot_ext.Sender(chosen, bc.tobytes(), max_count=count)
+    ch_dev = torch.from_numpy(cbn).cuda()
+    torch.cuda.synchronize()
+    assert R.receive_random(None, count, to_host=False, choices_dev=ch_dev.data_ptr()) == (None, None)
+    assert S.send_random(None, count, to_host=False, u_dev=R.ctx.u_dev) is None
+    R.ctx.sync()
+    S.ctx.sync()
+    u_ref, recv_ref = ot_ext.Receiver(pairs).receive_random(cbn.tobytes(), count)
+    sent_ref = ot_ext.Sender(chosen, bc.tobytes()).send_random(u_ref, count)
+
+    def dl(ptr, nbytes):
+        import ctypes as C
+        buf = np.empty(nbytes, dtype=np.uint8)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+        return buf
+    assert np.array_equal(dl(R.ctx.msgs_dev, count * 16).view(np.uint64).reshape(count, 2), recv_ref)
+    assert np.array_equal(dl(S.ctx.msgs_dev, count * 32).view(np.uint64).reshape(count, 2, 2), sent_ref)
+    assert np.array_equal(recv_ref, sent_ref[np.arange(count), bits])

@@ -68,6 +68,15 @@ __global__ void __launch_bounds__(1024) k_piece64(uint32_t *Z, uint32_t *out) {
     } else if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345678u) out[0] = v.x;
 }
 
+// 128-B pieces (8 lanes x 16 B) at a stride of 512 B, the four pieces of a word on four workgroups (k_conv_taylor with 32-row
+// tiles); for calibrating FETCH_SIZE
+__global__ void __launch_bounds__(1024) k_piece128(const uint32_t *Z, uint32_t *out) {
+    const uint32_t oct = threadIdx.x & 7, tq = blockIdx.x & 3;
+    const uint32_t word = (blockIdx.x >> 2) * 128 + (threadIdx.x >> 3);
+    const uint4 v = *(const uint4 *)(Z + (uint64_t)word * 128 + tq * 32 + oct * 4);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345678u) out[0] = v.x;
+}
+
 int main() {
     uint32_t *Z;
     const size_t bytes = 512ull << 20;
@@ -124,6 +133,14 @@ int main() {
             printf("%s 64-B pieces at stride 512 B, pieces of a word on %s: %.3f ms  %.2f TB/s\n", var & 2 ? "read+write" : "read only ",
                    var & 1 ? "one XCD   " : "eight XCDs", ms, (var & 2 ? 2.0 : 1.0) * bytes / ms * 1e-9);
         }
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_piece128, dim3(4 * 8192), dim3(1024), 0, 0, Z, Z);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("read only  128-B pieces at stride 512 B, pieces of a word on four XCDs: %.3f ms  %.2f TB/s\n", ms, bytes / ms * 1e-9);
+    }
     CK(hipGetLastError());
     return 0;
 }

@@ -6,7 +6,7 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --alsz-log2n 0 --lut-log2b 0"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ARGS --no-prof > $OUT/fetch.log 2>&1 || exit 2
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARGS --no-prof > $OUT/write.log 2>&1 || exit 3
