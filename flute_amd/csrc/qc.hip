@@ -570,14 +570,15 @@ __device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, 
 // are loaded while the current tile is being processed.
 template <bool INV>
 __global__ void __launch_bounds__(CT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8) {
+k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8, uint32_t nact) {
     __shared__ u4 lds[CU_LDS];
     __shared__ uint32_t mvl[CU_MAX_MOVES];  // the move list, staged once (a global load in P2 would drain the prefetch)
     const uint32_t su = threadIdx.x >> 2, quad = threadIdx.x & 3;  // owner mapping of part P3
     // INV: thread owns sub-unit su (8 words) x row quad; forward load: word wl = it >> 2 of pass i
+    // ntiles8 = units x nact: the first nact (8, or fewer in a sharded context: qc_set_rows_active) 16-row slices of a unit
     auto gptr = [&](uint32_t v) {
-        const uint32_t t = xcd_slice_order(v, 8, ntiles8);
-        return D + (uint64_t)(t >> 3) * 2048 * ROWS + (t & 7) * CT_ROWS;
+        const uint32_t t = xcd_slice_order(v, nact, ntiles8);
+        return D + (uint64_t)(t / nact) * 2048 * ROWS + (t & (nact - 1u)) * CT_ROWS;
     };
     uint32_t t = blockIdx.x;
     if (t >= ntiles8) return;
@@ -697,6 +698,7 @@ struct taylor_desc {
     uint32_t lg;   // log2(column stride in words): every shift of the tile's phases is a multiple of 2^lg words, so
                    // the words with equal index mod 2^lg form independent problems; a tile takes one residue g
     uint32_t nph;
+    uint32_t nact;  // row groups (of 4 << lrq rows) that hold data: 32 >> lrq, or fewer in a sharded context; a power of two
     uint8_t lchunk[8], lpw[8];
 };
 
@@ -751,7 +753,7 @@ __device__ __forceinline__ u4 ty_ld(const uint32_t *__restrict__ Din, const tayl
                                     uint32_t it) {
     const uint32_t UW = 1u << (t.lus - 5 - t.lg);  // columns per unit
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
-    const uint32_t nrg = 32u >> t.lrq;  // row groups
+    const uint32_t nrg = t.nact;  // row groups
     const uint32_t rg = b % nrg, g = (b / nrg) & ((1u << t.lg) - 1u), bc = (b / nrg) >> t.lg;
     const uint32_t cb = bc % ncoltiles, grp = bc / ncoltiles;
     const uint32_t o0 = cb * W;
@@ -784,7 +786,7 @@ __global__ void __launch_bounds__(CT_THREADS)
     __shared__ u4 lds[8192];
     const uint32_t UW = 1u << (t.lus - 5 - t.lg);  // columns per unit
     const uint32_t NC = 1u << t.lnc, W = NC - t.hw;
-    const uint32_t nrg = 32u >> t.lrq;  // row groups
+    const uint32_t nrg = t.nact;  // row groups
     const uint32_t items = 1u << (t.lnu + t.lnc + t.lrq);  // == 8192 (make_taylor)
     uint32_t vb = blockIdx.x;
     if (vb >= ntiles) return;
@@ -840,14 +842,15 @@ __global__ void __launch_bounds__(CT_THREADS)
 // of a 155 ms step at n = 2^26). Persistent with next-tile prefetch like k_conv_unit.
 struct wu_phases {
     uint32_t nub;  // log2(units)
+    uint32_t nact;  // row groups (of 4 << lq rows) that hold data: 32 >> lq, or fewer in a sharded context; a power of two
     uint32_t nph;
     uint8_t lchunk[32], lpw[32];  // log2 of chunk and pw in units; half = chunk / 2
 };
 // tile = all 2^nub units x one word offset x 2^lq row quads, lq = 13 - nub (4 quads = 64 B per unit at nub = 11, the
 // whole 512-B granule at nub = 8): always 8192 u4 = 128 KiB, [unit][quad]
-__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t lq, uint32_t vtile) {
-    const uint32_t tile = xcd_slice_order(vtile, 32u >> lq, 2048u << (5 - lq));
-    const uint32_t o = tile >> (5 - lq), rg = tile & ((32u >> lq) - 1u);
+__device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint32_t lq, uint32_t nact, uint32_t vtile) {
+    const uint32_t tile = xcd_slice_order(vtile, nact, 2048u * nact);
+    const uint32_t o = tile / nact, rg = tile & (nact - 1u);
     const uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
     auto ld = [&](uint32_t it) { return ld_u4(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & ((1u << lq) - 1u))); };
     cu_regs x;
@@ -859,10 +862,11 @@ __device__ __forceinline__ cu_regs wu_fetch(const uint32_t *__restrict__ D, uint
 __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__restrict__ D, wu_phases ph, int inverse) {
     __shared__ u4 lds[8192];  // [unit][quad]
     const uint32_t lq = 13 - ph.nub, qm = (1u << lq) - 1u;  // 8 <= nub <= 11 (run_conversion)
-    const uint32_t ntiles = 2048u << (5 - lq);
+    const uint32_t nact = ph.nact;
+    const uint32_t ntiles = 2048u * nact;
     uint32_t t = blockIdx.x;
     if (t >= ntiles) return;
-    cu_regs nx = wu_fetch(D, lq, t);
+    cu_regs nx = wu_fetch(D, lq, nact, t);
 #pragma unroll 1
     for (; t < ntiles; t += gridDim.x) {
         {
@@ -872,7 +876,7 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             lds[i + 7 * CT_THREADS] = nx.h;
         }
         __syncthreads();
-        nx = wu_fetch(D, lq, t + gridDim.x < ntiles ? t + gridDim.x : t);
+        nx = wu_fetch(D, lq, nact, t + gridDim.x < ntiles ? t + gridDim.x : t);
         for (uint32_t q = 0; q < ph.nph; q++) {
             const uint32_t pi = inverse ? ph.nph - 1 - q : q;
             const uint32_t lchunk = ph.lchunk[pi], lpw = ph.lpw[pi];
@@ -897,8 +901,8 @@ __global__ void __launch_bounds__(CT_THREADS) k_conv_wholeunits(uint32_t *__rest
             __syncthreads();
         }
         {
-            const uint32_t tt = xcd_slice_order(t, 32u >> lq, ntiles);
-            const uint32_t o = tt >> (5 - lq), rg = tt & ((32u >> lq) - 1u);
+            const uint32_t tt = xcd_slice_order(t, nact, ntiles);
+            const uint32_t o = tt / nact, rg = tt & (nact - 1u);
             uint32_t *g = D + (uint64_t)o * ROWS + (rg << (lq + 2));
             for (uint32_t it = threadIdx.x; it < 8192; it += CT_THREADS)
                 *(u4 *)(g + (uint64_t)(it >> lq) * 2048 * ROWS + 4 * (it & qm)) = lds[it];
@@ -951,6 +955,8 @@ struct tile_desc {
     uint32_t tmask;  // word-index bits that belong to the tile
     uint32_t pmw;    // word-index bits of the pruned levels
     uint32_t zero_bit;  // tile bit whose "1" half is known to be zero on input (forward transform of an operand); 32 = none
+    uint32_t rhalves;   // 2: both 64-row halves of every tile are processed; 1: only rows 0..63 hold data (a sharded
+                        // context of 4 or more ranks owns at most 64 bit rows: qc_set_rows_active), the grid is half as large
     uint32_t nlev;
     uint64_t posq;    // 5 bits per tile bit: its word-index bit (packed so that the kernels never index kernarg memory)
     uint32_t lev[8];  // r | tbit << 8 | np << 16 | pruned << 24
@@ -965,6 +971,9 @@ __device__ __forceinline__ uint32_t tile_base(const tile_desc &d, uint32_t o) {
         }
     return w;
 }
+// tile index -> (gather-tile number, row half) under d.rhalves
+__device__ __forceinline__ uint32_t tile_rh(const tile_desc &d, uint32_t idx) { return d.rhalves == 1 ? 0u : idx & 1u; }
+__device__ __forceinline__ uint32_t tile_no(const tile_desc &d, uint32_t idx) { return d.rhalves == 1 ? idx : idx >> 1; }
 __device__ __forceinline__ uint32_t tile_word(const tile_desc &d, uint32_t t) {
     uint32_t w = 0;
 #pragma unroll
@@ -1184,8 +1193,8 @@ __global__ void __launch_bounds__(TL_THREADS)
     __shared__ uint32_t lds[(1 << NB) * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t rh = blockIdx.x & 1;
-    const uint32_t base_w = tile_base(d, blockIdx.x >> 1);
+    const uint32_t rh = tile_rh(d, blockIdx.x);
+    const uint32_t base_w = tile_base(d, tile_no(d, blockIdx.x));
     tile_load<NB>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
     if (!INV && up.nsteps) tile_unit_phases<false>(lds, up, up.list);
@@ -1525,16 +1534,17 @@ __global__ void __launch_bounds__(TL_THREADS)
     if (idx >= ntiles) return;
     if (up.nsteps)
         for (uint32_t i = threadIdx.x; i < up.step_end[up.nsteps - 1]; i += TL_THREADS) mvl[i] = up.list[i];
-    typename tile_regs<(1 << NB) / TL_WAVES>::type v = tile_fetch<NB>(Z, d, tile_base(d, idx >> 1), idx & 1, wave, lane);
+    typename tile_regs<(1 << NB) / TL_WAVES>::type v =
+        tile_fetch<NB>(Z, d, tile_base(d, tile_no(d, idx)), tile_rh(d, idx), wave, lane);
 #pragma unroll 1
     for (; idx < ntiles; idx += gridDim.x) {
-        const uint32_t rh = idx & 1;
-        const uint32_t base_w = tile_base(d, idx >> 1);
+        const uint32_t rh = tile_rh(d, idx);
+        const uint32_t base_w = tile_base(d, tile_no(d, idx));
         tile_put<NB>(lds, v, d, wave, lane);
         __syncthreads();
         {
             const uint32_t nidx = idx + gridDim.x < ntiles ? idx + gridDim.x : idx;
-            v = tile_fetch<NB>(Z, d, tile_base(d, nidx >> 1), nidx & 1, wave, lane);
+            v = tile_fetch<NB>(Z, d, tile_base(d, tile_no(d, nidx)), tile_rh(d, nidx), wave, lane);
         }
         if (!INV && up.nsteps) tile_unit_phases<false>(lds, up, mvl);
         top_levels<INV>(lds, d.nb, TW, wave, lane);
@@ -1600,7 +1610,7 @@ __global__ void __launch_bounds__(MD_THREADS)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto fetch = [&](uint32_t idx) {
-        const uint32_t *g = Z + (uint64_t)(tile_base(d, idx >> 1) | tile_word(d, wave)) * ROWS + (idx & 1) * TL_ROWS + lane;
+        const uint32_t *g = Z + (uint64_t)(tile_base(d, tile_no(d, idx)) | tile_word(d, wave)) * ROWS + tile_rh(d, idx) * TL_ROWS + lane;
         regs_t v;
 #pragma unroll
         for (int i = 0; i < PER; i++) v[i] = g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS];
@@ -1608,16 +1618,20 @@ __global__ void __launch_bounds__(MD_THREADS)
     };
     // a workgroup takes BOTH row halves of a tile back to back (sequence s: tile pair blockIdx.x + (s / 2) gridDim.x,
     // half s % 2): the second half finds the tile's masks in L2
-    const uint32_t npairs = ntiles >> 1;
+    // (d.rhalves == 1: one tile index per gather tile, the sequence is simply blockIdx.x, + gridDim.x, ...)
+    const uint32_t RH = d.rhalves;
+    const uint32_t npairs = ntiles / RH;
     if (blockIdx.x >= npairs) return;
-    const uint32_t nseq = 2 * ((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    auto tile_of = [&](uint32_t sq) { return 2 * (blockIdx.x + (sq >> 1) * gridDim.x) + (sq & 1); };
+    const uint32_t nseq = RH * ((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    auto tile_of = [&](uint32_t sq) {
+        return RH == 2 ? 2 * (blockIdx.x + (sq >> 1) * gridDim.x) + (sq & 1) : blockIdx.x + sq * gridDim.x;
+    };
     uint32_t idx = tile_of(0);
     const uint32_t bf = wave;
     // the 4 x 1 KiB of masks of a tile (level lane / 16, line lane % 16), touched one tile ahead; pf stays live up to
     // the drain at the end of the kernel (see mask_prefetch)
     auto masks_ahead = [&](uint32_t &pf, uint32_t i2) {
-        const uint32_t o2 = pext32(tile_base(d, i2 >> 1), mask_hi);
+        const uint32_t o2 = pext32(tile_base(d, tile_no(d, i2)), mask_hi);
         mask_prefetch(pf, MT + ((((uint64_t)o2 * 4 + (lane >> 4)) * 8 + bf) << 8) + (lane & 15) * 16);
     };
     uint32_t pf = 0;
@@ -1626,8 +1640,8 @@ __global__ void __launch_bounds__(MD_THREADS)
 #pragma unroll 1
     for (uint32_t sq = 0; sq < nseq; sq++) {
         idx = tile_of(sq);
-        const uint32_t rh = idx & 1;
-        const uint32_t base_w = tile_base(d, idx >> 1);
+        const uint32_t rh = tile_rh(d, idx);
+        const uint32_t base_w = tile_base(d, tile_no(d, idx));
         const uint32_t outer = pext32(base_w, mask_hi);
 #pragma unroll
         for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
@@ -1635,7 +1649,7 @@ __global__ void __launch_bounds__(MD_THREADS)
         {
             const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
             v = fetch(nidx);
-            if (!QC_MIDMASK_LDS && !(nidx & 1)) masks_ahead(pf, nidx);
+            if (!QC_MIDMASK_LDS && !tile_rh(d, nidx)) masks_ahead(pf, nidx);
         }
         // QC_MIDMASK_LDS: the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and
         // parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
@@ -1800,7 +1814,9 @@ __global__ void __launch_bounds__(64 * NVW)
     // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
     // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
     uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
-    if (gridDim.x % 16 == 0) {
+    if (d.rhalves == 1) {
+        rh = 0, o = blockIdx.x;
+    } else if (gridDim.x % 16 == 0) {
         rh = (blockIdx.x >> 3) & 1;
         o = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
     }
@@ -1909,7 +1925,7 @@ __global__ void __launch_bounds__(64 * NVW)
 
 template <int MODE>
 static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
-    const dim3 g((1u << (d.m - 5 - d.nb)) * 2);
+    const dim3 g((1u << (d.m - 5 - d.nb)) * d.rhalves);
     switch (d.nb) {
         case 5: hipLaunchKernelGGL((k_fft_low<MODE, 1>), g, dim3(64), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
         case 6: hipLaunchKernelGGL((k_fft_low<MODE, 2>), g, dim3(128), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
@@ -1989,7 +2005,7 @@ static inline size_t fn_dyn_lds(uint32_t tail) {
 __global__ void __launch_bounds__(256)
     k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, const uint32_t *__restrict__ sb,
                 uint32_t sbpos, uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
-                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out) {
+                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out, uint32_t rows_active, uint32_t out_words) {
     __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
     // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
     extern __shared__ blk_t fn_dyn[];
@@ -2003,10 +2019,12 @@ __global__ void __launch_bounds__(256)
     for (uint32_t i = threadIdx.x; i < FN_W * ROWS; i += 256) {
         const uint64_t w = w0 + (i >> 7);
         const uint32_t row = i & 127;
+        // rows >= rows_active are zero by linearity and were not computed (sharded contexts): never read them
+        const bool live = row < rows_active;
         uint32_t v = 0;
-        if (w < nw) v = Z[w * ROWS + row];
+        if (w < nw && live) v = Z[w * ROWS + row];
         const uint64_t w1 = w + wsh;
-        if (w1 < nw) {
+        if (w1 < nw && live) {
             uint32_t lo = Z[w1 * ROWS + row];
             uint32_t hi1 = (sh && w1 + 1 < nw) ? Z[(w1 + 1) * ROWS + row] : 0u;
             v ^= sh ? ((lo >> sh) | (hi1 << (32 - sh))) : lo;
@@ -2066,7 +2084,14 @@ __global__ void __launch_bounds__(256)
                 r.x = XAND(r.x, u.x, m), r.y = XAND(r.y, u.y, m), r.z = XAND(r.z, u.z, m), r.w = XAND(r.w, u.w, m);
             }
         }
-        out[k] = r;
+        // out_words < 4: only the low 64 / 32 bits of an output hold data (slot Blocks of a sharded context of 4 / 8 ranks);
+        // they are stored packed, which is what travels in exchange #2
+        if (out_words == 4)
+            out[k] = r;
+        else if (out_words == 2)
+            ((uint2 *)out)[k] = make_uint2(r.x, r.y);
+        else
+            ((uint32_t *)out)[k] = r.x;
     }
 }
 
@@ -2111,7 +2136,14 @@ static inline uint32_t ilog2(uint64_t x) {
 // group A restricted to the phases pw = 2^pb_lo .. 2^pb_hi bits (5 <= pb_lo <= pb_hi <= R - 1) of an array of
 // 2^(R+16) bits per row. Its largest chunk spans 2^(pb_hi-4) units of 2^21 bits (one group); every shift is a multiple
 // of 2^(pb_lo-5) words = the column stride, so the halo is 2^(pb_hi-pb_lo+1) columns whatever R is.
-static bool make_taylor_a(uint32_t R, uint32_t pb_hi, uint32_t pb_lo, taylor_desc &t, unsigned &grid, uint32_t &ncol) {
+static uint32_t taylor_nact(uint32_t lrq, uint32_t rows_active) {
+    const uint32_t per = 4u << lrq, all = 32u >> lrq;
+    uint32_t need = (rows_active + per - 1) / per, n = 1;
+    while (n < need) n <<= 1;
+    return n < all ? n : all;
+}
+static bool make_taylor_a(uint32_t R, uint32_t pb_hi, uint32_t pb_lo, taylor_desc &t, unsigned &grid, uint32_t &ncol,
+                          uint32_t rows_active) {
     memset(&t, 0, sizeof t);
     if (pb_lo < 5 || pb_hi < pb_lo || pb_hi + 1 > R) return false;
     int lrq = 3;
@@ -2135,11 +2167,12 @@ static bool make_taylor_a(uint32_t R, uint32_t pb_hi, uint32_t pb_lo, taylor_des
     const uint32_t UW = 1u << (t.lus - 5 - t.lg), W = (1u << t.lnc) - t.hw;
     ncol = (UW + W - 1) / W;
     const uint32_t groups = 1u << (R - 5 - t.lnu);
-    grid = (groups * ncol * (32u >> t.lrq)) << t.lg;
+    t.nact = taylor_nact(t.lrq, rows_active);
+    grid = (groups * ncol * t.nact) << t.lg;
     return true;
 }
 
-static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid, uint32_t &ncol) {
+static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid, uint32_t &ncol, uint32_t rows_active) {
     memset(&t, 0, sizeof t);
     int lrq = 3;
     if (!groupA) {
@@ -2174,7 +2207,8 @@ static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid,
     const uint32_t UW = 1u << (t.lus - 5), W = (1u << t.lnc) - t.hw;
     ncol = (UW + W - 1) / W;
     const uint32_t groups = 1u << (R - (groupA ? R : t.lnu));
-    grid = groups * ncol * (32u >> t.lrq);
+    t.nact = taylor_nact(t.lrq, rows_active);
+    grid = groups * ncol * t.nact;
     return true;
 }
 
@@ -2198,6 +2232,10 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     }
     const unsigned grid = gridn(nwords * ROWS, 256, 1u << 20);
     const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * 8);
+    // row slices that hold data (sharded contexts of 4 or more ranks: qc_set_rows_active); powers of two
+    const uint32_t ra = c->rows_active;
+    const uint32_t nact16 = (ra + 15) / 16 >= 8 ? 8 : (ra + 15) / 16 > 2 ? 4 : (ra + 15) / 16;
+    const unsigned ugrid = (unsigned)((nwords >> (tb - 5)) * nact16);
     const int kid = inverse ? KID_CONV_INV : KID_CONV_FWD;
     const int kid_t = inverse ? KID_CONV_INV_TILE : KID_CONV_FWD_TILE;
     const uint32_t R = ell_elems > 16 ? ell_elems - 16 : 0;
@@ -2205,9 +2243,9 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     unsigned gA = 0, gB = 0;
     uint32_t ncA = 0, ncB = 0;
     const bool fused = R >= 1 && !(c->opts & SOT_OPT_NO_TOP);
-    const bool haveB = fused && make_taylor(R, false, tB, gB, ncB);
+    const bool haveB = fused && make_taylor(R, false, tB, gB, ncB, ra);
     const bool needA = R > 5;
-    bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA);
+    bool haveA = needA && haveB && make_taylor(R, true, tA, gA, ncA, ra);
     // R >= 11: one group-A tile would be half halo with 16-byte row spans (4.8 ms for one launch at R = 11, n = 2^26).
     // Split: A2 = the phases pw >= 2^9 bits on columns 16 words apart (halo 4 columns), then A = the R = 9 tile
     // geometry (pw = 2^8 .. 2^5) on groups of 16 units: 1.1 ms each. (At R = 10 the split measures the same as the
@@ -2220,7 +2258,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         taylor_desc lo, hi;
         unsigned glo = 0, ghi = 0;
         uint32_t nlo = 0, nhi = 0;
-        if (make_taylor_a(R, 8, 5, lo, glo, nlo) && make_taylor_a(R, R - 1, 9, hi, ghi, nhi)) {
+        if (make_taylor_a(R, 8, 5, lo, glo, nlo, ra) && make_taylor_a(R, R - 1, 9, hi, ghi, nhi, ra)) {
             tA = lo, gA = glo, ncA = nlo;
             tA2 = hi, gA2 = ghi, ncA2 = nhi;
             haveA2 = true;
@@ -2251,6 +2289,7 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         wu_phases w;
         memset(&w, 0, sizeof w);
         w.nub = nub;
+        w.nact = taylor_nact(13 - nub, ra);
         for (auto &p : units) {
             w.lchunk[w.nph] = (uint8_t)(ilog2(p.chunk) - 16);
             w.lpw[w.nph] = (uint8_t)(ilog2(p.pw) - 16);
@@ -2268,12 +2307,12 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
         if (!units_in_top) whole_units();
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_fwd, tgrid);
+            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(ugrid < c->num_cus ? ugrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_fwd, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(tgrid < c->num_cus ? tgrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_inv, tgrid);
+            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(ugrid < c->num_cus ? ugrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_inv, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) whole_units();
@@ -2299,6 +2338,7 @@ static tile_desc make_desc(uint32_t m, const std::vector<uint32_t> &plane_r, con
     memset(&d, 0, sizeof d);
     d.m = m;
     d.zero_bit = 32;
+    d.rhalves = 2;
     auto wb = [&](uint32_t r) { return m - r - 5; };
     for (uint32_t r : {1u, 2u, 4u, 8u, 16u}) d.pmw |= 1u << wb(r);
     std::vector<uint32_t> bits_r = plane_r;
@@ -2442,7 +2482,7 @@ static fft_plan make_plan(uint32_t m, uint32_t opts) {
     return p;
 }
 
-static inline unsigned tile_grid(const tile_desc &d) { return (unsigned)((1u << (d.m - 5 - d.nb)) * 2); }
+static inline unsigned tile_grid(const tile_desc &d) { return (unsigned)((1u << (d.m - 5 - d.nb)) * d.rhalves); }
 
 static void launch_tile(sot_ctx *c, int kid, bool inv, const tile_desc &d_in, uint32_t *Z, const unit_phases &up_in) {
     tile_desc d = d_in;
@@ -2480,7 +2520,7 @@ static void launch_w32(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32
     bool all32 = d.nb == 7;
     for (uint32_t l = 0; l < d.nlev; l++)
         if (((d.lev[l] >> 16) & 255u) != 5 || (d.lev[l] >> 24)) all32 = false;
-    if (!all32) {
+    if (!all32 || d.rhalves == 1) {  // the pair kernel exists to share scalar masks between the two row halves
         launch_tile(c, kid, inv, d, Z, up_none);
         return;
     }
@@ -2509,7 +2549,7 @@ static void launch_top(sot_ctx *c, int kid, bool inv, const tile_desc &d, uint32
 
 // forward butterflies of an operand (upper half of the row zero) on Z, up to (not including) the low kernel
 static inline unsigned mid_grid(const sot_ctx *c, const tile_desc &d) {
-    const unsigned np = tile_grid(d) / 2, cap = 2 * c->num_cus;  // tile pairs; two 64 KiB workgroups per CU
+    const unsigned np = tile_grid(d) / d.rhalves, cap = 2 * c->num_cus;  // tile pairs; two 64 KiB workgroups per CU
     return np < cap ? np : cap;
 }
 static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int upto = 3) {
@@ -2636,6 +2676,17 @@ int qc_init(sot_ctx *c) {
     return upload_a_and_transform(c);
 }
 
+// A sharded context of 4 or more ranks holds at most 64 bit rows (2 x 128 / world, both roles): the QC kernels then skip
+// the upper row half of every gather tile and the 16-row slices beyond `rows` in the conversion passes; k_qc_finish reads
+// the skipped rows as zero (they ARE zero: the encode is linear and those input rows are).
+void qc_set_rows_active(sot_ctx *c, uint32_t rows) {
+    c->rows_active = rows < ROWS ? rows : ROWS;
+    fft_plan *p = (fft_plan *)c->qc_plan;
+    const uint32_t rh = c->rows_active > TL_ROWS ? 2 : 1;
+    p->top.rhalves = p->mid1.rhalves = p->mid2.rhalves = p->low.rhalves = rh;
+    for (auto &d : p->w32) d.rhalves = rh;
+}
+
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
@@ -2656,7 +2707,7 @@ static int qc_set_points(sot_ctx *c, const uint64_t *points, uint64_t npoints) {
 
 // leaves V (Blocks, or slot Blocks of a sharded context) -> encoded Blocks out[0 .. n): load, forward transform,
 // pointwise multiply, inverse transform, finish. Asynchronous on the context's stream.
-static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32_t sbpos, blk_t *out) {
+static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32_t sbpos, blk_t *out, uint32_t out_words = 4) {
     const sot_conf &cf = c->conf;
     const qc_geom &g = c->g;
     const uint64_t nb128 = cf.n_blocks * 128;
@@ -2677,7 +2728,7 @@ static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     if (c->prof) prof_begin(c, KID_QC_FINAL);
     hipLaunchKernelGGL(k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                       g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out);
+                       g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
     if (c->prof) prof_end(c, KID_QC_FINAL);
     SOT_HIP(hipGetLastError());
     return SOT_OK;
@@ -2731,7 +2782,8 @@ int qc_encode_slots(sot_ctx *c, const uint64_t *points, uint64_t npoints, blk_t 
         SOT_TRY(qc_set_points(c, points, npoints));
         sb = c->sbv;
     }
-    SOT_TRY(qc_encode_core(c, c->sh.W, sb, c->sh.rpr, out));
+    // 2 x rpr live bits per output: whole Blocks at 2 ranks, 8 bytes at 4, 4 bytes at 8
+    SOT_TRY(qc_encode_core(c, c->sh.W, sb, c->sh.rpr, out, c->sh.rpr >= 64 ? 4 : c->sh.rpr >= 32 ? 2 : 1));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }

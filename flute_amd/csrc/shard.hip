@@ -11,8 +11,11 @@
 //   Block and role; what it keeps is its own slice. On arrival the slices of both roles are combined into "slot Blocks"
 //   W[leaf] = sender rows R_r | receiver rows R_r << rpr, so that one pass of the (lane = row) transform kernels serves
 //   2 * rpr rows: both directions multiply the same public polynomial a, all twiddle / multiplier masks are shared.
-// exchange #2 (all-to-all): the encoded slot Blocks of outputs [q * chunk, (q + 1) * chunk) go to rank q, which
-//   re-assembles whole Blocks B[k], A[k] from the `world` slices and runs the hashes / MT bits on its n_local outputs.
+// exchange #2 (all-to-all): the encoded slot Blocks of outputs [q * chunk, (q + 1) * chunk) go to rank q -- only their
+//   2 * rpr live bits, packed (32 / world bytes per output: k_qc_finish stores them that way) --, which re-assembles
+//   whole Blocks B[k], A[k] from the `world` slices and runs the hashes / MT bits on its n_local outputs.
+// With 4 or more ranks a rank holds at most 64 live bit rows: the transform kernels then skip the upper row half of every
+//   tile and the unused 16-row slices of the conversion passes (qc_set_rows_active).
 // The library moves no bytes between GPUs: the host (flute_amd/dist.py over torch.distributed = RCCL, or the Rust shim
 // over RCCL's ncclSend/ncclRecv) runs the two all-to-alls on the device buffers these entry points fill and consume.
 // Results are bit-identical to the one-GPU context for the same inputs (tests/test_gpu_shard.py).
@@ -149,7 +152,19 @@ __global__ void __launch_bounds__(256)
     for (uint64_t kk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; kk < n_local; kk += (uint64_t)gridDim.x * blockDim.x) {
         blk_t b = make_uint4(0, 0, 0, 0), a = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (uint32_t r = 0; r < (1u << LW); r++) slice_ops<LW>::put(b, a, r, recv[r * chunk + kk]);
+        for (uint32_t r = 0; r < (1u << LW); r++) {
+            // rank r's message: the 2 * rpr live bits of its slot Blocks, packed (16, 8 or 4 bytes per output)
+            blk_t slot = make_uint4(0, 0, 0, 0);
+            if (LW == 1) {
+                slot = recv[r * chunk + kk];
+            } else if (LW == 2) {
+                const uint2 t = ((const uint2 *)recv)[r * chunk + kk];
+                slot.x = t.x, slot.y = t.y;
+            } else {
+                slot.x = ((const uint32_t *)recv)[r * chunk + kk];
+            }
+            slice_ops<LW>::put(b, a, r, slot);
+        }
         B[kk] = b;
         A[kk] = a;
     }
@@ -186,9 +201,10 @@ int shard_init(sot_ctx *c, uint32_t rank, uint32_t world, int ggm_replicated) {
     s.k0 = (uint64_t)rank * s.chunk;
     s.n_local = s.k0 >= cf.n ? 0 : (cf.n - s.k0 < s.chunk ? cf.n - s.k0 : s.chunk);
     s.x1_bytes = ggm_replicated ? 0 : 2 * s.nk * s.nl_max * 128 * (16 / world);
-    s.x2_bytes = s.chunk * 16;
+    s.x2_bytes = s.chunk * (2 * s.rpr / 8);  // the 2 * rpr live bits of every slot Block
     if (!ggm_replicated) shard_sets_of((uint32_t)c->nsets, world, rank, &c->ggm_set0, &c->ggm_nsets);
     c->n_out = s.n_local;
+    qc_set_rows_active(c, 2 * s.rpr);  // slot Blocks: sender rows, receiver rows, zeros (world >= 4: at most 64 live rows)
     SOT_HIP(hipSetDevice(c->device));
     SOT_TRY(dev_alloc(c, (void **)&s.W, cf.cols * 128 * 16));
     return SOT_OK;
@@ -330,7 +346,8 @@ extern "C" int sot_shard_qc_encode(sot_ctx *c, const uint64_t *points, uint64_t 
     // outputs past n (the padding of the last ranks' chunks) are sent but never read; keep them defined
     const uint64_t total = (uint64_t)c->sh.world * c->sh.chunk;
     if (total > c->conf.n)
-        SOT_HIP(hipMemsetAsync((blk_t *)send_dev + c->conf.n, 0, (total - c->conf.n) * 16, c->stream));
+        SOT_HIP(hipMemsetAsync((uint8_t *)send_dev + c->conf.n * (2 * c->sh.rpr / 8), 0, (total - c->conf.n) * (2 * c->sh.rpr / 8),
+                               c->stream));
     SOT_TRY(qc_encode_slots(c, points, npoints, (blk_t *)send_dev));
     c->sh.enc_slots_ready = true;
     return SOT_OK;

@@ -145,6 +145,7 @@ struct sot_ctx {
     uint64_t rks_cap = 0;
     // QC scratch
     uint32_t *Z0 = nullptr, *Z1 = nullptr;  // bit rows [word][128 rows], ping-pong (the transform runs in place)
+    uint32_t rows_active = 128;             // bit rows that hold data (qc_set_rows_active)
     uint32_t *TW = nullptr, *TWC = nullptr; // twiddle matrix tables
     uint32_t *LM = nullptr;                 // per value word packed twiddle masks of the intra-word levels [nw/32][5][16][32]
     uint32_t *MT1 = nullptr, *MT2 = nullptr; // twiddle masks of the 16-plane passes (levels 9..12 / 13..16)
@@ -198,6 +199,7 @@ int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk
 
 // ---- qc.hip
 int qc_init(sot_ctx *c);
+void qc_set_rows_active(sot_ctx *c, uint32_t rows);
 void qc_free(sot_ctx *c);
 int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, int packed = 1, uint8_t *C_out = nullptr);
 // both roles of a sharded context at once: slot Blocks W -> slot-form outputs (the send buffer of exchange #2)
