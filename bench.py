@@ -385,8 +385,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="requested OTs per direction = 2^log2n")
     ap.add_argument("--threads", type=int, default=4,
                     help="rayon pool size the reference would use (roots depend on it, pprf.rs:115)")
-    ap.add_argument("--cpu-log2n", type=int, default=22,
-                    help="CPU baseline sample size (2^22: about 10-20 s in all on 16 cores, the one-worker leg included)")
+    ap.add_argument("--cpu-log2n", type=int, default=24,
+                    help="CPU baseline sample size (2^24 = the GPU workload itself: about 1.3 s on 16 cores with the "
+                         "reference's thread policy + about 13 s for the one-worker leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the RCCL all-gather that reassembles the party's MT store on every GPU")
