@@ -179,18 +179,18 @@ int dev_alloc(sot_ctx *c, void **p, uint64_t bytes) {
 
 extern "C" void sot_ctx_destroy(sot_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     qc_free(c);
     shard_free(c);
     void *ptrs[] = {c->role[0].V, c->role[0].enc, c->role[1].V, c->role[1].enc, c->lvl_a, c->lvl_b, c->sums,
                     c->d_base,    c->d_choices,   c->d_tg_sums, c->d_tg_last,   c->d_rks, c->d_mt,  c->d_tmp,
                     c->d_points,  c->d_chw};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     prof_resolve(c);
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

@@ -2692,7 +2692,7 @@ void qc_free(sot_ctx *c) {
     c->qc_plan = nullptr;
     void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->sbv, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
 }
 
 // noise indicator bit vector sb (one bit per leaf Block) from the receiver's interleaved points
