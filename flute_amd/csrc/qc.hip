@@ -410,55 +410,64 @@ __global__ void __launch_bounds__(CT_THREADS)
 // LDS index of (word, quad) = 36 * (word / 8) + 4 * (word % 8) + quad: 64 B of padding per sub-unit keeps the
 // 128-bit accesses of a quarter wave on distinct banks when threads own sub-units.
 #define UP_MAX_STEPS 64
-#define CU_LDS (2048 * 4 + 256 * 4)
 #define CU_MAX_MOVES 1536  // 12 sub-unit phases x at most 128 moves
-__device__ __forceinline__ uint32_t cu_idx(uint32_t word) { return (word << 2) + ((word >> 3) << 2); }
+// RQ = row quads per tile (4: 16 rows, 128 KiB + the move list, one workgroup of 1024 threads per CU; 2: 8 rows, 64 KiB,
+// workgroups of 512 threads, TWO per CU, so that one's barrier-separated LDS phases overlap the other's)
+#ifndef QC_CU_RQ
+#define QC_CU_RQ 2
+#endif
+template <int RQ>
+__device__ __forceinline__ uint32_t cu_idx(uint32_t word) { return (word + (word >> 3)) * RQ; }
 
+template <int RQ>
 __device__ __forceinline__ void cu_fold(u4 *lds, uint32_t lchunk, uint32_t lpw) {
+    constexpr uint32_t T = 256 * RQ;
     const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
     const uint32_t nchunks = 2048u >> (lchunk - 5);
     if (lpw >= 5) {
         const uint32_t pw_w = 1u << (lpw - 5);
-        const uint32_t items = nchunks * pw_w * 4;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & 3, wi = it >> 2;
+        const uint32_t items = nchunks * pw_w * RQ;
+        for (uint32_t it = threadIdx.x; it < items; it += T) {
+            uint32_t r = it % RQ, wi = it / RQ;
             uint32_t c = wi >> (lpw - 5), d = wi & (pw_w - 1);
             uint32_t base = c * chunk_w + half_w;
-            lds[cu_idx(base + d) + r] ^= lds[cu_idx(base + half_w - pw_w + d) + r];
+            lds[cu_idx<RQ>(base + d) + r] ^= lds[cu_idx<RQ>(base + half_w - pw_w + d) + r];
         }
     } else {
         const uint32_t pw = 1u << lpw;
-        const uint32_t items = nchunks * 4;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & 3, c = it >> 2;
+        const uint32_t items = nchunks * RQ;
+        for (uint32_t it = threadIdx.x; it < items; it += T) {
+            uint32_t r = it % RQ, c = it / RQ;
             uint32_t base = c * chunk_w + half_w;
-            lds[cu_idx(base) + r] ^= lds[cu_idx(base + half_w - 1) + r] >> (32 - pw);
+            lds[cu_idx<RQ>(base) + r] ^= lds[cu_idx<RQ>(base + half_w - 1) + r] >> (32 - pw);
         }
     }
 }
 
+template <int RQ>
 __device__ __forceinline__ void cu_shift(u4 *lds, uint32_t lchunk, uint32_t lpw) {
+    constexpr uint32_t T = 256 * RQ;
     const uint32_t chunk_w = 1u << (lchunk - 5), half_w = chunk_w >> 1;
-    const uint32_t items = 1024 * 4;
+    const uint32_t items = 1024 * RQ;
     if (lpw >= 5) {
         const uint32_t pw_w = 1u << (lpw - 5);
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & 3, wi = it >> 2;
+        for (uint32_t it = threadIdx.x; it < items; it += T) {
+            uint32_t r = it % RQ, wi = it / RQ;
             uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
             if (d >= pw_w) {
                 uint32_t base = c * chunk_w;
-                lds[cu_idx(base + d) + r] ^= lds[cu_idx(base + half_w + d - pw_w) + r];
+                lds[cu_idx<RQ>(base + d) + r] ^= lds[cu_idx<RQ>(base + half_w + d - pw_w) + r];
             }
         }
     } else {
         const uint32_t pw = 1u << lpw;
-        for (uint32_t it = threadIdx.x; it < items; it += CT_THREADS) {
-            uint32_t r = it & 3, wi = it >> 2;
+        for (uint32_t it = threadIdx.x; it < items; it += T) {
+            uint32_t r = it % RQ, wi = it / RQ;
             uint32_t c = wi >> (lchunk - 6), d = wi & (half_w - 1);
             uint32_t base = c * chunk_w;
-            u4 h = lds[cu_idx(base + half_w + d) + r] << pw;
-            if (d) h |= lds[cu_idx(base + half_w + d - 1) + r] >> (32 - pw);
-            lds[cu_idx(base + d) + r] ^= h;
+            u4 h = lds[cu_idx<RQ>(base + half_w + d) + r] << pw;
+            if (d) h |= lds[cu_idx<RQ>(base + half_w + d - 1) + r] >> (32 - pw);
+            lds[cu_idx<RQ>(base + d) + r] ^= h;
         }
     }
 }
@@ -556,7 +565,7 @@ struct cu_regs {
     u4 a, b, c, d, e, f, g, h;
 };
 template <bool INV>
-__device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, uint32_t quad) {
+__device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, uint32_t quad) {  // g: the tile's first row
     const uint32_t *p = g + (uint64_t)(INV ? 8 * su : su) * ROWS + 4 * quad;
     constexpr uint64_t st = (INV ? 1 : 256) * ROWS;
     cu_regs r;
@@ -565,43 +574,45 @@ __device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, 
     return r;
 }
 
-// Persistent: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the tile fills all of the
-// CU's LDS, so the only way to overlap HBM with the LDS phases is in time: the next tile's 32 registers per thread
-// are loaded while the current tile is being processed.
-template <bool INV>
-__global__ void __launch_bounds__(CT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8, uint32_t nact) {
-    __shared__ u4 lds[CU_LDS];
+// Persistent: workgroups walk tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the next tile's 32 registers per thread are
+// loaded while the LDS phases of the current one run (with RQ = 4 the tile fills the CU's LDS and this is the only
+// overlap there is; with RQ = 2 a second workgroup on the CU overlaps its phases with this one's barriers as well).
+template <bool INV, int RQ>
+__global__ void __launch_bounds__(256 * RQ) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t nact) {
+    constexpr uint32_t T = 256 * RQ;      // threads
+    constexpr uint32_t SU = 9 * RQ;       // u4 per sub-unit in LDS: 8 words x RQ quads + one word of padding
+    constexpr uint32_t LANES = 8 * RQ;    // u4 of a sub-unit = lanes per move in P2
+    __shared__ u4 lds[(2048 + 256) * RQ];
     __shared__ uint32_t mvl[CU_MAX_MOVES];  // the move list, staged once (a global load in P2 would drain the prefetch)
-    const uint32_t su = threadIdx.x >> 2, quad = threadIdx.x & 3;  // owner mapping of part P3
-    // INV: thread owns sub-unit su (8 words) x row quad; forward load: word wl = it >> 2 of pass i
-    // ntiles8 = units x nact: the first nact (8, or fewer in a sharded context: qc_set_rows_active) 16-row slices of a unit
+    const uint32_t su = threadIdx.x / RQ, quad = threadIdx.x % RQ;  // owner mapping of part P3
+    // ntiles = units x nact: the first nact (32 / RQ, or fewer in a sharded context: qc_set_rows_active) slices of 4 RQ rows
     auto gptr = [&](uint32_t v) {
-        const uint32_t t = xcd_slice_order(v, nact, ntiles8);
-        return D + (uint64_t)(t / nact) * 2048 * ROWS + (t & (nact - 1u)) * CT_ROWS;
+        const uint32_t t = xcd_slice_order(v, nact, ntiles);
+        return D + (uint64_t)(t / nact) * 2048 * ROWS + (t & (nact - 1u)) * (4 * RQ);
     };
     uint32_t t = blockIdx.x;
-    if (t >= ntiles8) return;
-    for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += CT_THREADS) mvl[i] = mv.list[i];
+    if (t >= ntiles) return;
+    for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += T) mvl[i] = mv.list[i];
     cu_regs nx = cu_load_tile<INV>(gptr(t), su, quad);
 #pragma unroll 1
-    for (; t < ntiles8; t += gridDim.x) {
+    for (; t < ntiles; t += gridDim.x) {
         uint32_t *g = gptr(t);
         {
             u4 w[8] = {nx.a, nx.b, nx.c, nx.d, nx.e, nx.f, nx.g, nx.h};
             if (!INV) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) lds[cu_idx(su + 256 * j) + quad] = w[j];
+                for (int j = 0; j < 8; j++) lds[cu_idx<RQ>(su + 256 * j) + quad] = w[j];
             } else {
                 reg_phases<true, u4>(w);
 #pragma unroll
-                for (int j = 0; j < 8; j++) lds[36 * su + 4 * j + quad] = w[j];
+                for (int j = 0; j < 8; j++) lds[SU * su + RQ * j + quad] = w[j];
             }
         }
         __syncthreads();
         {  // next tile: in flight during the LDS phases (the last iteration re-reads its own tile: unconditional
            // loads keep w[] in registers)
-            nx = cu_load_tile<INV>(gptr(t + gridDim.x < ntiles8 ? t + gridDim.x : t), su, quad);
+            nx = cu_load_tile<INV>(gptr(t + gridDim.x < ntiles ? t + gridDim.x : t), su, quad);
         }
         // P2 forward comes after P1, inverse before it
         for (int part = 0; part < 2; part++) {
@@ -610,27 +621,27 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8, uint32_t n
                 for (int q = 0; q < 8; q++) {
                     const uint32_t lpw = INV ? q : 7 - q, lchunk = lpw + 9;
                     if (!INV) {
-                        cu_fold(lds, lchunk, lpw);
+                        cu_fold<RQ>(lds, lchunk, lpw);
                         __syncthreads();
-                        cu_shift(lds, lchunk, lpw);
+                        cu_shift<RQ>(lds, lchunk, lpw);
                     } else {
-                        cu_shift(lds, lchunk, lpw);
+                        cu_shift<RQ>(lds, lchunk, lpw);
                         __syncthreads();
-                        cu_fold(lds, lchunk, lpw);
+                        cu_fold<RQ>(lds, lchunk, lpw);
                     }
                     __syncthreads();
                 }
             } else {
-                const uint32_t x = threadIdx.x & 31, grp = threadIdx.x >> 5;
+                const uint32_t x = threadIdx.x % LANES, grp = threadIdx.x / LANES;
                 uint32_t start = 0;
                 for (uint32_t st = 0; st < mv.nsteps; st++) {
                     const uint32_t end = mv.step_end[st];
-                    for (uint32_t it = start + grp; it < end; it += CT_THREADS / 32) {  // entries: see PH_ENTRY
+                    for (uint32_t it = start + grp; it < end; it += T / LANES) {  // entries: see PH_ENTRY
                         const uint32_t e = mvl[it];
-                        const uint32_t a = 36 * (e & 1023u) + x, c = 36 * ((e >> 10) & 1023u) + x;
+                        const uint32_t a = SU * (e & 1023u) + x, c = SU * ((e >> 10) & 1023u) + x;
                         u4 h = lds[a];
                         if (e >> 30) {
-                            const u4 gg = lds[36 * ((e >> 20) & 1023u) + x];
+                            const u4 gg = lds[SU * ((e >> 20) & 1023u) + x];
                             if (!INV) h ^= gg;
                             lds[a] = INV ? h ^ gg : h;
                         }
@@ -644,7 +655,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8, uint32_t n
         if (!INV) {
             u4 o[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = lds[36 * su + 4 * j + quad];
+            for (int j = 0; j < 8; j++) o[j] = lds[SU * su + RQ * j + quad];
             // one row at a time: the prefetched tile already holds 32 registers
             {
                 uint32_t x[8];
@@ -673,7 +684,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles8, uint32_t n
             for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(8 * su + j) * ROWS + 4 * quad) = o[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(su + 256 * j) * ROWS + 4 * quad) = lds[cu_idx(su + 256 * j) + quad];
+            for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(su + 256 * j) * ROWS + 4 * quad) = lds[cu_idx<RQ>(su + 256 * j) + quad];
         }
         __syncthreads();  // the tile's LDS is free again
     }
@@ -2234,8 +2245,9 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
     const unsigned tgrid = (unsigned)((nwords >> (tb - 5)) * 8);
     // row slices that hold data (sharded contexts of 4 or more ranks: qc_set_rows_active); powers of two
     const uint32_t ra = c->rows_active;
-    const uint32_t nact16 = (ra + 15) / 16 >= 8 ? 8 : (ra + 15) / 16 > 2 ? 4 : (ra + 15) / 16;
+    const uint32_t nact16 = taylor_nact(QC_CU_RQ == 4 ? 2 : 1, ra);  // slices of 4 QC_CU_RQ rows
     const unsigned ugrid = (unsigned)((nwords >> (tb - 5)) * nact16);
+    const unsigned ucap = (QC_CU_RQ == 4 ? 1 : 2) * c->num_cus;  // resident workgroups
     const int kid = inverse ? KID_CONV_INV : KID_CONV_FWD;
     const int kid_t = inverse ? KID_CONV_INV_TILE : KID_CONV_FWD_TILE;
     const uint32_t R = ell_elems > 16 ? ell_elems - 16 : 0;
@@ -2307,12 +2319,12 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
         if (!units_in_top) whole_units();
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<false>, dim3(ugrid < c->num_cus ? ugrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_fwd, ugrid, nact16);
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<false, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_fwd, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, k_conv_unit<true>, dim3(ugrid < c->num_cus ? ugrid : c->num_cus), dim3(CT_THREADS), bufs[cur], *sub_inv, ugrid, nact16);
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<true, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_inv, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) whole_units();
