@@ -86,9 +86,19 @@ __global__ void k_set_points(uint32_t *__restrict__ sb, const uint64_t *__restri
 }
 // V[idx], with bit `sbpos` := sb[idx] when sb != nullptr (receiver with packed choice bits: sbpos = 0, the receiver's
 // bit row 0; in the slot Blocks of a sharded context the receiver's row 0 is slot 128 / world of rank 0, shard.hip)
+// lw = words per stored leaf: 4 (whole Blocks), or 2 / 1 for the slot Blocks of a sharded context of 4 / 8 ranks, which
+// hold 64 / 32 live bits and are stored packed (kernel-uniform)
 __device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t idx, const uint32_t *__restrict__ sb,
-                                         uint32_t sbpos) {
-    blk_t v = V[idx];
+                                         uint32_t sbpos, uint32_t lw = 4) {
+    blk_t v;
+    if (lw == 4) {
+        v = V[idx];
+    } else if (lw == 2) {
+        const uint2 t = ((const uint2 *)V)[idx];
+        v = make_uint4(t.x, t.y, 0, 0);
+    } else {
+        v = make_uint4(((const uint32_t *)V)[idx], 0, 0, 0);
+    }
     if (sb) {
         const uint32_t sh = sbpos & 31u, m = ~(1u << sh), b = ((sb[idx >> 5] >> (idx & 31)) & 1u) << sh;
         switch (sbpos >> 5) {  // kernel-uniform
@@ -163,16 +173,16 @@ __global__ void __launch_bounds__(256)
 #define LD_T 128
 __global__ void __launch_bounds__(LD_T)
     k_qc_load(const blk_t *__restrict__ V, const uint32_t *__restrict__ sb, uint32_t sbpos, uint64_t v1_len, uint64_t P,
-              uint64_t lo_bits, uint64_t nw_half, uint32_t *__restrict__ Z) {
+              uint64_t lo_bits, uint64_t nw_half, uint32_t *__restrict__ Z, uint32_t rows_active, uint32_t lw) {
     __shared__ uint32_t tio[LD_W * 132];  // in: [w][p][q] words (stride 132); out: [w][row] (stride 129)
     const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
     for (uint32_t i = threadIdx.x; i < LD_W * 32; i += LD_T) {
         const uint64_t c = w0 * 32 + i;
         blk_t v = make_uint4(0, 0, 0, 0);
         if (c < lo_bits) {
-            v = ld_leaf(V, v1_len + c, sb, sbpos);  // V1 = V + nb128 and v1_len == nb128
+            v = ld_leaf(V, v1_len + c, sb, sbpos, lw);  // V1 = V + nb128 and v1_len == nb128
             if (c + P < v1_len) {
-                blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos);
+                blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos, lw);
                 v.x ^= u.x, v.y ^= u.y, v.z ^= u.z, v.w ^= u.w;
             }
         }
@@ -181,19 +191,27 @@ __global__ void __launch_bounds__(LD_T)
     }
     __syncthreads();
     {
+        // rows >= rows_active hold no data (sharded contexts, qc_set_rows_active) and are never read: their quarter of the
+        // Block words is neither transposed nor written
         const uint32_t wl = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const bool live = 32 * q < rows_active;
         uint32_t a[32];
+        if (live) {
 #pragma unroll
-        for (int p = 0; p < 32; p++) a[p] = tio[wl * 132 + p * 4 + q];
-        transpose32(a);
+            for (int p = 0; p < 32; p++) a[p] = tio[wl * 132 + p * 4 + q];
+            transpose32(a);
+        }
         __syncthreads();
+        if (live) {
 #pragma unroll
-        for (int b = 0; b < 32; b++) tio[wl * 129 + 32 * q + b] = a[b];
+            for (int b = 0; b < 32; b++) tio[wl * 129 + 32 * q + b] = a[b];
+        }
     }
     __syncthreads();
+    const uint32_t rows_w = rows_active > 96 ? 128 : rows_active > 64 ? 96 : rows_active > 32 ? 64 : 32;  // whole quarters
     for (uint32_t i = threadIdx.x; i < LD_W * ROWS; i += LD_T) {
         const uint64_t w = w0 + (i >> 7);
-        if (w < nw_half) Z[w * ROWS + (i & 127)] = tio[(i >> 7) * 129 + (i & 127)];
+        if (w < nw_half && (i & 127) < rows_w) Z[w * ROWS + (i & 127)] = tio[(i >> 7) * 129 + (i & 127)];
     }
 }
 
@@ -1988,10 +2006,10 @@ __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64
 //                                         ^ sum_{j < tail} a_lo[(k - S - j) mod P] V1'[S + j]
 // V0 = V[0 .. nb128), V1' = (V1 mod x^P - 1). a2 = a' repeated twice as a bit vector.
 __device__ __forceinline__ blk_t ld_v1p(const blk_t *V, const uint32_t *sb, uint32_t sbpos, uint64_t v1_len, uint64_t P,
-                                        uint64_t c) {
-    blk_t v = ld_leaf(V, v1_len + c, sb, sbpos);  // V1 = V + nb128, v1_len == nb128
+                                        uint64_t c, uint32_t lw) {
+    blk_t v = ld_leaf(V, v1_len + c, sb, sbpos, lw);  // V1 = V + nb128, v1_len == nb128
     if (c + P < v1_len) {
-        blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos);
+        blk_t u = ld_leaf(V, v1_len + c + P, sb, sbpos, lw);
         v.x ^= u.x;
         v.y ^= u.y;
         v.z ^= u.z;
@@ -2048,10 +2066,10 @@ __global__ void __launch_bounds__(256)
         for (uint32_t x = threadIdx.x; x < FN_K + tail - 1; x += 256) {
             uint64_t cc = c0 + x;
             if (cc >= P) cc -= P;
-            win[x] = ld_v1p(V, sb, sbpos, nb128, P, cc);
+            win[x] = ld_v1p(V, sb, sbpos, nb128, P, cc, out_words);
             abit[x] = cc < S ? (uint8_t)(0u - ((a2[cc >> 5] >> (cc & 31)) & 1u)) : (uint8_t)0;
         }
-        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V, sb, sbpos, nb128, P, S + j);
+        for (uint32_t j = threadIdx.x; j < tail; j += 256) hi[j] = ld_v1p(V, sb, sbpos, nb128, P, S + j, out_words);
     }
     __syncthreads();
     {
@@ -2060,9 +2078,14 @@ __global__ void __launch_bounds__(256)
         const bool act = threadIdx.x < FN_W * 4 && !(QC_EXP & 8);
         uint32_t a[32];
         if (act) {
+            if (32 * q < rows_active) {
 #pragma unroll
-            for (int b = 0; b < 32; b++) a[b] = tio[wl * 129 + 32 * q + b];
-            transpose32(a);
+                for (int b = 0; b < 32; b++) a[b] = tio[wl * 129 + 32 * q + b];
+                transpose32(a);
+            } else {  // a quarter of dead rows: word q of every Block is zero
+#pragma unroll
+                for (int b = 0; b < 32; b++) a[b] = 0;
+            }
         }
         __syncthreads();
         if (act) {
@@ -2076,10 +2099,10 @@ __global__ void __launch_bounds__(256)
         if (k >= n) break;
         const uint32_t *sp = tio + (kl >> 5) * 132 + (kl & 31) * 4;
         blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        blk_t u = ld_leaf(V, k, sb, sbpos);
+        blk_t u = ld_leaf(V, k, sb, sbpos, out_words);
         r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         if (k + P < nb128) {
-            u = ld_leaf(V, k + P, sb, sbpos);
+            u = ld_leaf(V, k + P, sb, sbpos, out_words);
             r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         }
         if (tail && !(QC_EXP & 4)) {
@@ -2095,8 +2118,8 @@ __global__ void __launch_bounds__(256)
                 r.x = XAND(r.x, u.x, m), r.y = XAND(r.y, u.y, m), r.z = XAND(r.z, u.z, m), r.w = XAND(r.w, u.w, m);
             }
         }
-        // out_words < 4: only the low 64 / 32 bits of an output hold data (slot Blocks of a sharded context of 4 / 8 ranks);
-        // they are stored packed, which is what travels in exchange #2
+        // out_words < 4: only the low 64 / 32 bits of a leaf and of an output hold data (slot Blocks of a sharded context of
+        // 4 / 8 ranks); both are stored packed (ld_leaf), and the packed outputs are what travels in exchange #2
         if (out_words == 4)
             out[k] = r;
         else if (out_words == 2)
@@ -2729,7 +2752,7 @@ static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32
         return SOT_EINVAL;
     }
     SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
-               g.nw / 2, c->Z0);
+               g.nw / 2, c->Z0, c->rows_active, out_words);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);

@@ -114,6 +114,16 @@ __global__ void __launch_bounds__(256)
 }
 
 // exchange #1, receiving side: recv = [source rank r][the message above]; W[leaf] = slot Block
+// slot Blocks are stored with their 2 * rpr live bits only: 16 / 8 / 4 bytes per leaf at 2 / 4 / 8 ranks (ld_leaf, qc.hip)
+template <int LW>
+__device__ __forceinline__ void st_slot(blk_t *W, uint64_t idx, blk_t v) {
+    if (LW == 1)
+        W[idx] = v;
+    else if (LW == 2)
+        ((uint2 *)W)[idx] = make_uint2(v.x, v.y);
+    else
+        ((uint32_t *)W)[idx] = v.x;
+}
 template <int LW>
 __global__ void __launch_bounds__(256)
     k_unpack_leaves(const unsigned char *__restrict__ recv, shard_geom g, uint64_t x1_bytes, blk_t *__restrict__ W) {
@@ -132,7 +142,7 @@ __global__ void __launch_bounds__(256)
         const uint64_t c = set0 + sl + (uint64_t)g.nsets * k;
         if (sl >= nl || c >= g.cols) continue;
         const T *src = (const T *)(recv + r * x1_bytes);
-        W[128 * c + j] = slice_ops<LW>::slots(src[lc], src[rs + lc]);
+        st_slot<LW>(W, 128 * c + j, slice_ops<LW>::slots(src[lc], src[rs + lc]));
     }
 }
 
@@ -141,7 +151,7 @@ template <int LW>
 __global__ void __launch_bounds__(256)
     k_slots_local(const blk_t *__restrict__ V0, const blk_t *__restrict__ V1, uint32_t rank, uint64_t nV, blk_t *__restrict__ W) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nV; i += (uint64_t)gridDim.x * blockDim.x)
-        W[i] = slice_ops<LW>::slots(slice_ops<LW>::get(V0[i], rank), slice_ops<LW>::get(V1[i], rank));
+        st_slot<LW>(W, i, slice_ops<LW>::slots(slice_ops<LW>::get(V0[i], rank), slice_ops<LW>::get(V1[i], rank)));
 }
 
 // exchange #2, receiving side: recv = [source rank r][kk < chunk] slot Blocks of outputs k0 + kk (rows R_r of B in slots
