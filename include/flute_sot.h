@@ -15,7 +15,13 @@
  *    bitpolymul2/encode.c:102, bitpolymul.c:77).
  *  - "host" pointers are ordinary caller-owned memory; results stay resident in HBM inside the
  *    context until a *_download / output pointer asks for them.
- *  - a context may be used from one host thread at a time; two contexts may run concurrently.
+ *  - every entry point that takes a context holds that context's lock for the duration of the call: the sender and the
+ *    receiver direction of a party may be driven from two host threads at once, as gmw/src/mul_triple/silent_ot.rs:87-91
+ *    does -- the calls serialise (both directions share the context's stream and scratch buffers); two contexts run
+ *    concurrently. sot_and_circ_* lock the context their circuit was created on, sot_alsz_ctx_* their own context.
+ *  - the library links the HIP runtime (libamdhip64). A process that also loads another copy of that runtime -- PyTorch
+ *    ships its own -- must load that one first; the first runtime loaded serves every later user, and the other order
+ *    leaves the second user without devices ("No HIP GPUs"). flute_amd/lib.py imports torch before the library for this.
  *  - cites are relative to /root/reference/crates.
  */
 #ifndef FLUTE_SOT_H
