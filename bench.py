@@ -123,6 +123,37 @@ def aes128_workloads(fa, n, ms_per_step, lut):
     return out
 
 
+def lut_online_bench(fa, cs, lam, B, reps):
+    """FLUTE online LUT evaluation of the same batch on the subset products the setup layers just left in
+    HBM: both parties' delta shares of the 8 outputs of every sbox8 instance, reconstructed and checked against the
+    plaintext table (to_eval/sbox8.lut = the FIPS-197 S-box; tests/golden/sbox8_lut.json)."""
+    path = os.path.join(ROOT, "tests", "golden", "sbox8_lut.json")
+    tabs = []
+    for l in json.load(open(path))["luts"]:
+        v = int(l["table_hex"], 16)
+        tabs.append([(v >> (255 - j)) & 1 for j in range(256)])  # Msb0 bits of the big-endian number (lut_circuit.rs:355-399)
+    tmpl = fa.LutTemplate([(tuple(range(8)), t) for t in tabs])
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 2, (B, 8), dtype=np.uint8)
+    m = x ^ lam[0].reshape(B, 8) ^ lam[1].reshape(B, 8)
+    rows = tmpl.rows(m)
+    o = [rng.integers(0, 2, (B, 8), dtype=np.uint8) for _ in range(2)]
+    total = 0.0
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        d0 = fa.online_delta_shares(cs[0], tmpl, B, rows, o[0], 0)
+        d1 = fa.online_delta_shares(cs[1], tmpl, B, rows, o[1], 1)
+        if rep:
+            total += time.perf_counter() - t0
+    ok = bool(np.array_equal(d0 ^ d1 ^ o[0] ^ o[1], tmpl.plain(x)))
+    dt = total / reps
+    return {"metric": "FLUTE online LUT evaluation, sbox8.lut instances/s (both parties' delta shares on one GPU)",
+            "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "batch": B, "ms_per_batch": dt * 1e3,
+            "outputs_equal_plaintext_sbox": ok,
+            "note": "wall time of the two calls incl. upload of the masked inputs / output-lambda shares and download of the "
+                    "delta shares (1 byte per gate and instance each way) and per-call device allocation"}
+
+
 def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, log2b, reps):
     """FLUTE function-dependent setup (aby2_lut.rs:699-783) for `log2b` (a count) instances of to_eval/sbox8.lut (one grouped
     8-input LUT with 8 outputs = 8 LUT gates, 247 AND gates in 7 layers per instance) on the triples just expanded:
@@ -165,10 +196,16 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
         prod = v0 ^ v1
         ok = bool(np.array_equal(prod[circ.n_inputs:], prod[circ.x_src] & prod[circ.y_src]) and
                   np.array_equal(prod[:circ.n_inputs], ins[0] ^ ins[1]))
+        online = None
+        try:
+            online = lut_online_bench(fa, cs, ins, B, reps)
+        except Exception as e:  # secondary figure
+            online = {"value": None, "note": "failed: %r" % (e,)}
         for c in cs:
             c.close()
         dt = total / reps
-        return {"metric": "FLUTE LUT setup, sbox8.lut instances/s (both parties' AND layers on one GPU)",
+        return {"online": online,
+                "metric": "FLUTE LUT setup, sbox8.lut instances/s (both parties' AND layers on one GPU)",
                 "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "and_gates_per_s": 247 * B / dt,
                 "batch": B, "ms_per_batch": dt * 1e3, "layers": int(circ.n_layers), "mts_consumed": int(circ.n_gates),
                 "subset_products_correct": ok, "host_circuit_build_s": t_build,

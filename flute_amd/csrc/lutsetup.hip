@@ -305,3 +305,157 @@ extern "C" int sot_and_circ_values(sot_and_circ *q, uint8_t *bits_out) {
 }
 
 extern "C" uint64_t sot_mt_remaining(const sot_ctx *c) { return c && c->mt_valid ? c->mt_rem : 0; }
+
+// ================================================================================================
+// FLUTE ONLINE LUT evaluation: LutGate::compute_delta_share (aby2_lut.rs:209-277) for `batch` SIMD
+// instances of a template of LUT gates (flute_benchmark batches sub-circuits this way, bench.rs:367-384), on the subset
+// products the setup circuit above left in HBM.
+//
+// For one gate with p inputs, truth table T (row index j: input i is bit p-1-i of j, aby2_lut.rs:959), public masked
+// inputs m and shared lambdas, the reference XORs, over the subsets q of the inputs, [XOR over the set rows j of
+// AND_{i in q} x_i[j]] & share(prod_{i not in q} lambda_i), x_i[j] = !m_i ^ j_i (expand, :947-964). AND_{i in q} x_i[j] = 1
+// iff j agrees with m on q, so with g(j') = T[j' ^ m] the bracket is Z[~q] for Z = the subset-sum (zeta) transform of g
+// over GF(2), and the party's share of the output value is parity(Z & L), L[s] = its share of prod_{i in s} lambda_i
+// (L[0] = 1 for party 1 only: the reference's whole_set_mask, :265-270). Per thread: one XOR-permutation of the table by
+// m, one 2^p-point zeta transform on <= 8 words, 2^p - 1 share bits gathered from the value store.
+// The reference's bitvec_and_fold (:1177-1188) folds from all-false, which zeroes every term (its tests are #[ignore]d);
+// this computes the protocol as specified -- see oracle/lut_eval_oracle.py for the restatement it is tested against.
+//
+// lsrc[g][s], 0 < s < 2^p: where L[s] lives for template gate g: 0 << 24 | i = setup input i of the instance
+// (|s| = 1), (l + 1) << 24 | r = the gate of rank r among the template's gates of setup layer l.
+__global__ void __launch_bounds__(256)
+    k_lut_online(const uint64_t *__restrict__ vals, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                 const uint32_t *__restrict__ arity, const uint32_t *__restrict__ tt, const uint32_t *__restrict__ lsrc,
+                 const uint64_t *__restrict__ lbase, const uint32_t *__restrict__ tcount,
+                 const uint8_t *__restrict__ masked_in, const uint8_t *__restrict__ lam_out, uint32_t party,
+                 uint8_t *__restrict__ out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint64_t)batch * n_luts) return;
+    const uint32_t inst = (uint32_t)(idx / n_luts), g = (uint32_t)(idx % n_luts);
+    const uint32_t p = arity[g], nrow = 1u << p, nw = nrow > 32 ? nrow >> 5 : 1;
+    const uint32_t m = masked_in[idx] & (nrow - 1u);
+    uint32_t G[8];
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w++) G[w] = w < nw ? tt[g * 8 + (w ^ (m >> 5))] : 0u;
+    // g(j') = T[j' ^ m] inside the words: swap the halves of every 2^(b+1)-block for the set bits b of m
+#pragma unroll
+    for (uint32_t b = 0; b < 5; b++) {
+        const uint32_t M = b == 0 ? 0x55555555u : b == 1 ? 0x33333333u : b == 2 ? 0x0F0F0F0Fu : b == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+        if ((m >> b) & 1u) {
+#pragma unroll
+            for (uint32_t w = 0; w < 8; w++) G[w] = ((G[w] & M) << (1u << b)) | ((G[w] >> (1u << b)) & M);
+        }
+    }
+    // Z[s] = XOR of g over the subsets of s
+#pragma unroll
+    for (uint32_t b = 0; b < 5; b++) {
+        const uint32_t M = b == 0 ? 0x55555555u : b == 1 ? 0x33333333u : b == 2 ? 0x0F0F0F0Fu : b == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+        if (b < p) {
+#pragma unroll
+            for (uint32_t w = 0; w < 8; w++) G[w] ^= (G[w] & M) << (1u << b);
+        }
+    }
+#pragma unroll
+    for (uint32_t wb = 0; wb < 3; wb++) {
+        if (5 + wb < p) {
+#pragma unroll
+            for (uint32_t w = 0; w < 8; w++)
+                if ((w >> wb) & 1u) G[w] ^= G[w ^ (1u << wb)];
+        }
+    }
+    uint32_t acc = G[0] & party;  // L[0]
+    const uint32_t *src = lsrc + (uint64_t)g * 256;
+#pragma unroll
+    for (uint32_t w = 0; w < 8; w++) {
+        if (w < nw) {
+            const uint32_t z = G[w];
+            const uint32_t hi = nrow < 32 ? nrow : 32;
+#pragma unroll 4
+            for (uint32_t b = (w == 0 ? 1 : 0); b < hi; b++) {
+                const uint32_t e = src[w * 32 + b], l1 = e >> 24, r = e & 0xFFFFFFu;
+                const uint64_t pos = l1 == 0 ? (uint64_t)inst * n_in + r : lbase[l1 - 1] + (uint64_t)inst * tcount[l1 - 1] + r;
+                acc ^= (z >> b) & bit_at(vals, pos);
+            }
+        }
+    }
+    out[idx] = (uint8_t)((acc ^ lam_out[idx]) & 1u);
+}
+
+// host/device scratch of one call, freed on every path
+struct le_bufs {
+    void *p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    int up(void **out, const void *src, uint64_t bytes, hipStream_t st) {
+        *out = nullptr;
+        if (hipMalloc(out, bytes ? bytes : 16) != hipSuccess) {
+            sot_set_error("lut_online: hipMalloc(%llu bytes) failed", (unsigned long long)bytes);
+            return SOT_ENOMEM;
+        }
+        p[n++] = *out;
+        if (src && bytes) SOT_HIP(hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, st));
+        return SOT_OK;
+    }
+    ~le_bufs() {
+        for (int i = 0; i < n; i++) (void)hipFree(p[i]);
+    }
+};
+
+extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t batch, uint32_t n_luts, uint32_t n_in, const uint32_t *arity,
+                                   const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                                   const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id,
+                                   uint8_t *delta_share_out) {
+    if (!q || !batch || !n_luts || !arity || !tt || !lsrc || (!tcount && q->n_layers) || !masked_in || !lam_out ||
+        party_id > 1 || !delta_share_out)
+        return SOT_EINVAL;
+    sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    // the store must hold the evaluated setup circuit of exactly `batch` instances of the template
+    if ((uint64_t)batch * n_in != q->n_inputs) {
+        sot_set_error("lut_online: %u instances x %u setup inputs != the circuit's %u inputs", batch, n_in, q->n_inputs);
+        return SOT_EINVAL;
+    }
+    for (uint32_t l = 0; l < q->n_layers; l++) {
+        if ((uint64_t)batch * tcount[l] != q->count[l]) {
+            sot_set_error("lut_online: setup layer %u has %u gates, not %u instances x %u", l, q->count[l], batch, tcount[l]);
+            return SOT_EINVAL;
+        }
+        if (!q->evaluated[l]) {
+            sot_set_error("lut_online: setup layer %u is not evaluated yet", l);
+            return SOT_ESTATE;
+        }
+    }
+    for (uint32_t g = 0; g < n_luts; g++) {
+        if (arity[g] < 1 || arity[g] > 8) {
+            sot_set_error("lut_online: LUT %u has %u inputs (1 .. 8 supported)", g, arity[g]);
+            return SOT_EINVAL;
+        }
+        for (uint32_t s = 1; s < (1u << arity[g]); s++) {
+            const uint32_t e = lsrc[(uint64_t)g * 256 + s], l1 = e >> 24, r = e & 0xFFFFFFu;
+            if (l1 == 0 ? r >= n_in : (l1 > q->n_layers || r >= tcount[l1 - 1])) {
+                sot_set_error("lut_online: LUT %u subset %u points outside the setup circuit", g, s);
+                return SOT_EINVAL;
+            }
+        }
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t items = (uint64_t)batch * n_luts;
+    le_bufs b;
+    uint32_t *d_ar, *d_tt, *d_ls, *d_tc;
+    uint64_t *d_lb;
+    uint8_t *d_m, *d_lo, *d_out;
+    SOT_TRY(b.up((void **)&d_ar, arity, (uint64_t)n_luts * 4, c->stream));
+    SOT_TRY(b.up((void **)&d_tt, tt, (uint64_t)n_luts * 32, c->stream));
+    SOT_TRY(b.up((void **)&d_ls, lsrc, (uint64_t)n_luts * 1024, c->stream));
+    SOT_TRY(b.up((void **)&d_tc, tcount, (uint64_t)q->n_layers * 4, c->stream));
+    SOT_TRY(b.up((void **)&d_lb, q->base.data(), (uint64_t)q->n_layers * 8, c->stream));
+    SOT_TRY(b.up((void **)&d_m, masked_in, items, c->stream));
+    SOT_TRY(b.up((void **)&d_lo, lam_out, items, c->stream));
+    SOT_TRY(b.up((void **)&d_out, nullptr, items, c->stream));
+    const uint64_t grid = (items + 255) / 256;
+    hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, batch, n_luts, n_in, d_ar, d_tt,
+                       d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipMemcpyAsync(delta_share_out, d_out, items, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
