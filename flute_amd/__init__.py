@@ -10,6 +10,7 @@ from .silent_ot import (QuasiCyclicConf, Engine, ShardedEngine, Sender, Receiver
                         sample_base_choice_bits, fake_base)
 from .mul_triple import MulTriples, SilentMtProvider  # noqa: F401
 from .lut_eval import LutTemplate, online_delta_shares  # noqa: F401
+from .aes_lut import Aes128Flute  # noqa: F401
 from .lut_setup import (SetupCircuit, build_setup_circuit, replicate_setup_circuit, AndCircuit,  # noqa: F401
                         aes128_lut_gate_parents, aes128_setup_circuit, gmw_and_layers, AES128_SBOXES,
                         AES128_LUT_SETUP_MTS, AES128_BRISTOL_AND_GATES)

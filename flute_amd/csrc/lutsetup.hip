@@ -324,14 +324,14 @@ extern "C" uint64_t sot_mt_remaining(const sot_ctx *c) { return c && c->mt_valid
 // lsrc[g][s], 0 < s < 2^p: where L[s] lives for template gate g: 0 << 24 | i = setup input i of the instance
 // (|s| = 1), (l + 1) << 24 | r = the gate of rank r among the template's gates of setup layer l.
 __global__ void __launch_bounds__(256)
-    k_lut_online(const uint64_t *__restrict__ vals, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+    k_lut_online(const uint64_t *__restrict__ vals, uint32_t inst0, uint32_t batch, uint32_t n_luts, uint32_t n_in,
                  const uint32_t *__restrict__ arity, const uint32_t *__restrict__ tt, const uint32_t *__restrict__ lsrc,
                  const uint64_t *__restrict__ lbase, const uint32_t *__restrict__ tcount,
                  const uint8_t *__restrict__ masked_in, const uint8_t *__restrict__ lam_out, uint32_t party,
                  uint8_t *__restrict__ out) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint64_t)batch * n_luts) return;
-    const uint32_t inst = (uint32_t)(idx / n_luts), g = (uint32_t)(idx % n_luts);
+    const uint32_t inst = inst0 + (uint32_t)(idx / n_luts), g = (uint32_t)(idx % n_luts);  // instance of the setup circuit
     const uint32_t p = arity[g], nrow = 1u << p, nw = nrow > 32 ? nrow >> 5 : 1;
     const uint32_t m = masked_in[idx] & (nrow - 1u);
     uint32_t G[8];
@@ -400,7 +400,8 @@ struct le_bufs {
     }
 };
 
-extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t batch, uint32_t n_luts, uint32_t n_in, const uint32_t *arity,
+extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                                   const uint32_t *arity,
                                    const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
                                    const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id,
                                    uint8_t *delta_share_out) {
@@ -409,14 +410,17 @@ extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t batch, uint32_t n_l
         return SOT_EINVAL;
     sot_ctx *c = q->ctx;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    // the store must hold the evaluated setup circuit of exactly `batch` instances of the template
-    if ((uint64_t)batch * n_in != q->n_inputs) {
-        sot_set_error("lut_online: %u instances x %u setup inputs != the circuit's %u inputs", batch, n_in, q->n_inputs);
+    // the store must hold the evaluated setup circuit of N instances of the template, N >= first_instance + batch
+    const uint64_t ninst = n_in ? q->n_inputs / n_in : 0;
+    if (!n_in || ninst * n_in != q->n_inputs || (uint64_t)first_instance + batch > ninst) {
+        sot_set_error("lut_online: instances %u .. %u of a setup circuit with %u inputs = %llu instances x %u", first_instance,
+                      first_instance + batch, q->n_inputs, (unsigned long long)ninst, n_in);
         return SOT_EINVAL;
     }
     for (uint32_t l = 0; l < q->n_layers; l++) {
-        if ((uint64_t)batch * tcount[l] != q->count[l]) {
-            sot_set_error("lut_online: setup layer %u has %u gates, not %u instances x %u", l, q->count[l], batch, tcount[l]);
+        if (ninst * tcount[l] != q->count[l]) {
+            sot_set_error("lut_online: setup layer %u has %u gates, not %llu instances x %u", l, q->count[l],
+                          (unsigned long long)ninst, tcount[l]);
             return SOT_EINVAL;
         }
         if (!q->evaluated[l]) {
@@ -452,7 +456,7 @@ extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t batch, uint32_t n_l
     SOT_TRY(b.up((void **)&d_lo, lam_out, items, c->stream));
     SOT_TRY(b.up((void **)&d_out, nullptr, items, c->stream));
     const uint64_t grid = (items + 255) / 256;
-    hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, batch, n_luts, n_in, d_ar, d_tt,
+    hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, first_instance, batch, n_luts, n_in, d_ar, d_tt,
                        d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipMemcpyAsync(delta_share_out, d_out, items, hipMemcpyDeviceToHost, c->stream));

@@ -112,7 +112,7 @@ def load_library():
     L.sot_and_circ_layer_eval.argtypes = [P, u32, u32, P, P]
     L.sot_and_circ_layer_eval_peer.argtypes = [P, u32, u32, P]
     L.sot_and_circ_values.argtypes = [P, P]
-    L.sot_lut_online_eval.argtypes = [P, u32, u32, u32, P, P, P, P, P, P, u32, P]
+    L.sot_lut_online_eval.argtypes = [P, u32, u32, u32, u32, P, P, P, P, P, P, u32, P]
     L.sot_mt_remaining.argtypes = [P]
     L.sot_alsz_receive.argtypes = [i32, P, P, u64, P, P]
     L.sot_alsz_send.argtypes = [i32, P, P, P, u64, P]

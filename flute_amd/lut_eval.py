@@ -86,16 +86,17 @@ class LutTemplate:
         return np.stack([np.asarray(self.tables[g], dtype=np.uint8)[r[:, g]] for g in range(self.n_luts)], axis=1)
 
 
-def online_delta_shares(and_circuit, template, batch, masked_rows, lam_out, party_id):
+def online_delta_shares(and_circuit, template, batch, masked_rows, lam_out, party_id, first_instance=0):
     """LutGate::compute_delta_share for every (instance, gate): this party's delta share bits [batch, n_luts]; the public
     output Delta is the XOR of the two parties' arrays (evaluate_interactive, aby2_lut.rs:145-165).
-    and_circuit: the party's AndCircuit of template.setup_circuit(batch) with every layer evaluated; masked_rows: the
+    and_circuit: the party's AndCircuit of template.setup_circuit(N) with every layer evaluated, of which instances
+    first_instance .. first_instance + batch - 1 are evaluated here (N = batch by default); masked_rows: the
     public masked inputs as row indices (template.rows); lam_out: its shares of the output lambdas [batch, n_luts]."""
     t = template
     m = np.ascontiguousarray(masked_rows, dtype=np.uint8).reshape(batch, t.n_luts)
     lo = np.ascontiguousarray(lam_out, dtype=np.uint8).reshape(batch, t.n_luts)
     out = np.zeros((batch, t.n_luts), dtype=np.uint8)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    check(and_circuit.engine.lib.sot_lut_online_eval(and_circuit.h, batch, t.n_luts, t.setup.n_inputs, p(t.arity), p(t.tt),
+    check(and_circuit.engine.lib.sot_lut_online_eval(and_circuit.h, first_instance, batch, t.n_luts, t.setup.n_inputs, p(t.arity), p(t.tt),
                                                      p(t.lsrc), p(t.tcount), p(m), p(lo), party_id, p(out)))
     return out

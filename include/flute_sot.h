@@ -202,7 +202,8 @@ int sot_and_circ_layer_eval_peer(sot_and_circ *circ, uint32_t layer, uint32_t pa
 int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
 /* FLUTE ONLINE LUT evaluation: LutGate::compute_delta_share (aby2_lut.rs:209-277, expand :947-964) for
  * `batch` SIMD instances of a template of n_luts LUT gates, on the subset products that the evaluated setup circuit
- * `circ` (of batch x the template's setup circuit, instance-major) holds in HBM. arity[g] = inputs of gate g (1 .. 8);
+ * `circ` (of N x the template's setup circuit, instance-major) holds in HBM: instances first_instance .. first_instance +
+ * batch - 1 of it (one call per LUT layer of a deeper circuit whose layers were set up together). arity[g] = inputs of gate g (1 .. 8);
  * tt[g][8]: its truth table, bit (j & 31) of word j >> 5 = output for row j (input i = bit arity-1-i of j, the reference's
  * row order); lsrc[g][256]: for every non-empty subset s of the row bits where this party's share of the product of those
  * inputs' lambdas lives: i for setup input i of the instance (one input), (l + 1) << 24 | r for the gate of rank r among
@@ -211,9 +212,9 @@ int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
  * the bits of Msg::Delta; the public output is the XOR of both parties' (:145-165). NOTE: the reference's own AND-fold
  * (:1177-1188) starts from all-false and zeroes every term (its tests are #[ignore]d); this computes the protocol as
  * specified -- parity unpinned, checked against the plaintext LUT value instead (tests/test_gpu_lut_eval.py). */
-int sot_lut_online_eval(sot_and_circ *circ, uint32_t batch, uint32_t n_luts, uint32_t n_in, const uint32_t *arity,
-                        const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount, const uint8_t *masked_in,
-                        const uint8_t *lam_out, uint32_t party_id, uint8_t *delta_share_out);
+int sot_lut_online_eval(sot_and_circ *circ, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                        const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                        const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id, uint8_t *delta_share_out);
 /* triples left in the context's store (MulTriples::len after the split_off_last calls so far) */
 uint64_t sot_mt_remaining(const sot_ctx *ctx);
 

@@ -116,3 +116,36 @@ def test_online_evaluation_refuses_bad_calls(fa):
     finally:
         e0.close()
         e1.close()
+
+
+def test_aes128_flute_end_to_end_fips197(fa):
+    """BASELINE config 4 end to end on the GPU: silent-OT triples -> function-dependent setup of all 200 S-boxes of two
+    AES-128 instances (98 800 triples) -> ten online LUT rounds (Delta shares exchanged per round) -> the FIPS-197
+    appendix C.1 ciphertext for instance 0 and a random key / plaintext pair checked against a plain AES for instance 1.
+    (Also a CPU cross-check of the composition itself: the same walk with a table S-box gives the same bytes.)"""
+    from flute_amd import aes_lut as al
+    from oracle import lut_eval_oracle as le
+    from tests.test_lut_eval import _aes_sbox
+    d = json.load(open(os.path.join(HERE, "golden", "sbox8_lut.json")))
+    tabs = [le.table_bits(l["table_hex"], 8) for l in d["luts"]]
+    batch = 2
+    aes = al.Aes128Flute(tabs, batch)
+    assert aes.setup_circuit.n_gates == batch * fa.AES128_LUT_SETUP_MTS
+    rng = np.random.default_rng(2024)
+    key = np.stack([np.arange(16, dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)])
+    pt = np.stack([np.array([0x11 * i for i in range(16)], dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)])
+    S = np.array(_aes_sbox(), dtype=np.uint8)
+    want = al.bits_to_bytes(al.aes128_walk(al.bytes_to_bits(pt), al.bytes_to_bits(key),
+                                           lambda r, x: al.bytes_to_bits(S[al.bits_to_bytes(x)]), True))
+    assert want[0].tobytes().hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"  # FIPS-197 C.1
+    e0, e1, _ = _two_providers(fa, 100000, 2, 77)
+    try:
+        lam_in = aes.offline(rng)
+        c0, c1 = _run_setup(fa, e0, e1, aes.setup_circuit, lam_in[0], lam_in[1])
+        assert e0.lib.sot_mt_remaining(e0.h) == 100000 - batch * fa.AES128_LUT_SETUP_MTS
+        got = aes.online([c0, c1], pt, key)
+        assert aes.rounds_run == 10
+        assert np.array_equal(got, want), (got[0].tobytes().hex(), want[0].tobytes().hex())
+    finally:
+        e0.close()
+        e1.close()

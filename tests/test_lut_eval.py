@@ -95,3 +95,21 @@ def test_delta_shares_reconstruct_the_sbox():
             d0 = le.compute_delta_share(0, tabs[k], m, lam0, e0, o0)
             d1 = le.compute_delta_share(1, tabs[k], m, lam1, e1, o1)
             assert (d0 ^ d1) ^ (o0 ^ o1) == le.plain_eval(tabs[k], xin)
+
+
+def test_aes128_lut_circuit_walk_is_fips197():
+    """flute_amd/aes_lut.py: the XOR-linear wiring around the 200 S-boxes, with a table S-box in place of the LUT protocol:
+    FIPS-197 appendix C.1; and the lambda walk (no constants) is the linear part of the same map"""
+    from flute_amd import aes_lut as al
+    S = np.array(_aes_sbox(), dtype=np.uint8)
+    key = np.arange(16, dtype=np.uint8)[None]
+    pt = np.array([0x11 * i for i in range(16)], dtype=np.uint8)[None]
+    calls = []
+
+    def sbox(rnd, x):
+        calls.append((rnd, x.shape))
+        return al.bytes_to_bits(S[al.bits_to_bytes(x)])
+    ct = al.bits_to_bytes(al.aes128_walk(al.bytes_to_bits(pt), al.bytes_to_bits(key), sbox, True))
+    assert ct.tobytes().hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"
+    assert [c[0] for c in calls] == list(range(10)) and all(c[1] == (1, 20, 8) for c in calls)
+    assert 10 * 20 == 200  # AES128_SBOXES of flute_amd/lut_setup.py
