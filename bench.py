@@ -120,6 +120,9 @@ def aes128_workloads(fa, n, ms_per_step, lut):
         # the AND layers themselves (both parties on this GPU): sbox8 instances/s measured above / 200
         out["flute_aes_instances_per_s_setup_layers"] = lut["value"] / fa.AES128_SBOXES
         out["flute_setup_batch_aes_instances"] = lut["batch"] / fa.AES128_SBOXES
+        if lut.get("online") and lut["online"].get("value"):
+            # the online LUT rounds of the same S-boxes (both parties, per-call transfers included) / 200
+            out["flute_aes_instances_per_s_online_luts"] = lut["online"]["value"] / fa.AES128_SBOXES
     return out
 
 
