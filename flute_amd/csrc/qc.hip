@@ -171,9 +171,13 @@ __global__ void __launch_bounds__(256)
 // buffer used in place (the kernel is latency bound: small workgroups, many per CU).
 #define LD_W 32
 #define LD_T 128
+// FULL: all 128 rows live and whole-Block leaves (every context but the sharded ones of 4 or more ranks): rows_active and
+// lw are compile-time constants, the kernel is the one-GPU kernel unchanged
+template <bool FULL>
 __global__ void __launch_bounds__(LD_T)
     k_qc_load(const blk_t *__restrict__ V, const uint32_t *__restrict__ sb, uint32_t sbpos, uint64_t v1_len, uint64_t P,
-              uint64_t lo_bits, uint64_t nw_half, uint32_t *__restrict__ Z, uint32_t rows_active, uint32_t lw) {
+              uint64_t lo_bits, uint64_t nw_half, uint32_t *__restrict__ Z, uint32_t rows_active_, uint32_t lw_) {
+    const uint32_t rows_active = FULL ? ROWS : rows_active_, lw = FULL ? 4u : lw_;
     __shared__ uint32_t tio[LD_W * 132];  // in: [w][p][q] words (stride 132); out: [w][row] (stride 129)
     const uint64_t w0 = (uint64_t)blockIdx.x * LD_W;
     for (uint32_t i = threadIdx.x; i < LD_W * 32; i += LD_T) {
@@ -2031,10 +2035,12 @@ __device__ __forceinline__ blk_t ld_v1p(const blk_t *V, const uint32_t *sb, uint
 static inline size_t fn_dyn_lds(uint32_t tail) {
     return tail ? (size_t)(FN_K + 2 * tail) * 16 + ((FN_K + tail + 15) & ~15u) : 0;
 }
+template <bool FULL>  // as in k_qc_load
 __global__ void __launch_bounds__(256)
     k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, const uint32_t *__restrict__ sb,
                 uint32_t sbpos, uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
-                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out, uint32_t rows_active, uint32_t out_words) {
+                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out, uint32_t rows_active_, uint32_t out_words_) {
+    const uint32_t rows_active = FULL ? ROWS : rows_active_, out_words = FULL ? 4u : out_words_;
     __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
     // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
     extern __shared__ blk_t fn_dyn[];
@@ -2751,8 +2757,13 @@ static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32
         sot_set_error("internal: tail exceeds FN_TAILMAX");
         return SOT_EINVAL;
     }
-    SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
-               g.nw / 2, c->Z0, c->rows_active, out_words);
+    const bool full = c->rows_active == ROWS && out_words == 4;
+    if (full)
+        SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<true>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
+                   g.nw / 2, c->Z0, c->rows_active, out_words);
+    else
+        SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<false>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
+                   g.nw / 2, c->Z0, c->rows_active, out_words);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
@@ -2762,8 +2773,12 @@ static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32
     fft_inverse_upper(c, zb[cur], plan);
     cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     if (c->prof) prof_begin(c, KID_QC_FINAL);
-    hipLaunchKernelGGL(k_qc_finish, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                       g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
+    if (full)
+        hipLaunchKernelGGL(k_qc_finish<true>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
+                           g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
+    else
+        hipLaunchKernelGGL(k_qc_finish<false>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
+                           g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
     if (c->prof) prof_end(c, KID_QC_FINAL);
     SOT_HIP(hipGetLastError());
     return SOT_OK;
