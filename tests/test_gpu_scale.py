@@ -208,3 +208,31 @@ def test_large_sizes_match_oracle(orc, log2n):
     if orc.ref_lib() is None:
         pytest.skip("oracle/_ref absent")
     _encode_both_vs_oracle(orc, 1 << log2n, 4, log2n, receiver=True, hashes=True)
+
+
+def test_unpacked_mode_at_the_headline_size():
+    """ChoiceBitPacking::False at n = 2^24 (k_sparse_choice over 120 shifts of a' at full length) through what does not
+    need the oracle: check_correlated with the explicit choice vector (silent_ot/mod.rs:744-777), and agreement with the
+    packed mode, which the tests above hold bit-exact against the oracle at this size: bit 0 of the packed A is C, the
+    other 127 bit rows are the same."""
+    import flute_amd as fa
+    n, T = 1 << 24, 4
+    eng = fa.Engine(n)
+    try:
+        rng = np.random.default_rng(2424)
+        msg2, msg, choices = fa.fake_base(eng.conf, rng)
+        delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        seed = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+        snd = fa.Sender.new_with_silent_base_ots(eng, msg2, T)
+        rcv = fa.Receiver.new_with_silent_base_ots(eng, msg, choices, T)
+        B = snd.correlated_silent_send(delta, seed)
+        A, Cv = rcv.correlated_silent_receive(snd.tree_groups, choice_bit_packing=False)
+        assert Cv.dtype == np.uint8 and Cv.shape == (n,) and 0.45 * n < int(Cv.sum()) < 0.55 * n
+        sel = Cv.astype(bool)
+        assert np.array_equal(A[~sel], B[~sel]) and np.array_equal(A[sel], B[sel] ^ delta)
+        A_packed = rcv.correlated_silent_receive(snd.tree_groups)
+        assert np.array_equal(A_packed[:, 0] & np.uint64(1), Cv.astype(np.uint64))
+        assert np.array_equal(A_packed[:, 0] >> np.uint64(1), A[:, 0] >> np.uint64(1))
+        assert np.array_equal(A_packed[:, 1], A[:, 1])
+    finally:
+        eng.close()
