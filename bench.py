@@ -6,10 +6,11 @@ what flute_benchmark's `time_silent_ots_ms` covers, bench.rs:274-278) for n = 2^
 one sender expansion + one receiver expansion (GGM/PPRF -> QuasiCyclic encode) + fused CR hashes and
 MT-bit derivation, after the base-OT seeds exist. value = 2n * steps / time ("times two because both
 parties generate this amount", bench.rs:271-272).
-N > 1 (default --mode strong): that ONE expansion is sharded over the ranks -- tree sets in the GGM stage, bit rows of
-both roles in the QC stage, output ranges in the hash stage, two RCCL all-to-alls between the stages and an all-gather
-of the MT words (csrc/shard.hip, flute_amd/dist.py); the gathered result is bit-identical to the one-GPU result, which
-rank 0 checks after the timed region (--no-verify to skip). --mode weak: independent instances per rank, value
+N > 1 (default --mode strong): that ONE step is split over the ranks. N = 2: by direction -- rank 0 runs the sender
+instance, rank 1 the receiver instance, one all-gather of two bit vectors per rank joins them (RoleSplitPipeline). N = 4, 8
+(or --split rows): tree sets in the GGM stage, bit rows of both roles in the QC stage, output ranges in the hash stage, two
+RCCL all-to-alls between the stages and an all-gather of the MT words (csrc/shard.hip, flute_amd/dist.py). Either way the
+result is bit-identical to the one-GPU result, which rank 0 checks after the timed region (--no-verify to skip). --mode weak: independent instances per rank, value
 aggregated over ranks.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched through torch.distributed.run)
@@ -291,6 +292,94 @@ def load_pmc():
         return None
 
 
+def roles_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
+    """N = 2 by direction (default there): rank 0 runs the party's sender instance, rank 1 its receiver instance, on
+    ordinary one-GPU contexts; the only traffic is one all-gather of two bit vectors per rank (RoleSplitPipeline)."""
+    eng = fa.Engine(n, device=local_rank)
+    conf = eng.conf
+    rng = np.random.default_rng(fd.instance_seed(0))  # the SAME instance on both ranks
+    x = fa.fake_base(conf, rng)
+    y = fa.fake_base(conf, rng)
+    delta, seed, delta_peer, seed_peer = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    # the peer party's TreeGrps for direction Y (received over mpc_channel in the reference): only rank 1 needs them
+    tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads) if rank == 1 else (None, None)
+    pts = eng.points(y[2])
+    pipe = fd.RoleSplitPipeline(eng, rank)
+    res = {}
+
+    def step():
+        pipe.direction(x[0], delta, seed, args.threads, y[1], y[2], tg_y[0], tg_y[1], pts)
+        if not args.no_gather:
+            res["mt"] = pipe.join()
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        fd.barrier(world)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = fd.max_over_ranks(time.perf_counter() - t0, world, device="cuda")
+    prof = {}
+    if not args.no_prof:
+        eng.prof_reset()
+        eng.prof_enable(True)
+        barrier()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        eng.prof_enable(False)
+        prof = eng.prof_read()
+    verified = None
+    if not args.no_verify and not args.no_gather:
+        ok = 1
+        if rank == 0:  # this GPU's context is a whole one: run both directions on it and compare the joined store
+            tg_full = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads)
+            eng.sender_expand(x[0], delta, seed, args.threads)
+            eng.qc_encode(0)
+            eng.receiver_expand(y[1], y[2], *tg_full)
+            eng.qc_encode(1, pts)
+            want = np.stack(eng.mt_bits(delta))
+            ok = int(np.array_equal(res["mt"].cpu().numpy().view(np.uint64), want))
+        t = torch.tensor([ok], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        verified = bool(t.item())
+    if rank == 0:
+        out = {
+            "metric": "random OTs/sec for 2^%d silent-OT expansion (sender+receiver per party, MT bits)" % args.log2n,
+            "value": 2.0 * n * args.steps / dt, "unit": "OTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 bitwise (GF(2)/AES, 128-bit blocks)", "data": "synthetic",
+            "config": {"workload": "zappot silent OT, QuasiCyclic scaler 2, ONE party's n=2^%d precompute_mts (sender + "
+                                   "receiver instance, MT bits) over 2 GPUs" % args.log2n,
+                       "P": conf.P, "trees": conf.parts, "depth": conf.depth, "threads_T": args.threads,
+                       "sharding": "by direction: rank 0 the sender instance, rank 1 the receiver instance (all trees, all 128 "
+                                   "bit rows each); all-gather of 2 bit vectors per rank (%d B each way per step)%s" % (
+                                       2 * ((n + 63) // 64) * 8, "" if not args.no_gather else " (skipped)")},
+            "sharded_equals_one_gpu": verified,
+        }
+        if prof:
+            per_step = {k: (ms / args.steps, cnt // args.steps) for k, (ms, cnt) in prof.items()}
+            qc_ms = sum(ms for k, (ms, _) in per_step.items() if k in QC_KERNELS)
+            dom_name, (dom_ms, dom_cnt) = max(per_step.items(), key=lambda kv: kv[1][0])
+            achieved = QC_BYTES_PER_OT * n / (qc_ms * 1e-3) / 1e9 if qc_ms else None
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                "kernel": dom_name, "kernel_avg_ms": dom_ms / max(dom_cnt, 1), "kernel_launches_per_step": dom_cnt,
+                "basis": "rank 0 (sender direction), QC-encode stage: 48 B/OT x n / summed device time of the stage's "
+                         "kernels per step (%.3f ms); traffic not collected in multi-GPU runs" % qc_ms}
+            out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    dist.destroy_process_group()
+
+
 def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
     """N > 1, one expansion over all ranks (BASELINE config 3). Every rank holds the same inputs (one party's base OTs,
     delta, seeds: in the reference they come from the base-OT phase and the party's RNG, both outside the hot path)."""
@@ -441,6 +530,9 @@ def main():
     ap.add_argument("--ggm", choices=("auto", "shard", "replicate"), default="auto",
                     help="strong mode: tree sets sharded over the ranks + exchange #1, or every rank expands all trees "
                          "(auto: replicate at 2 ranks, where one xGMI link would carry the whole leaf exchange)")
+    ap.add_argument("--split", choices=("auto", "rows", "roles"), default="auto",
+                    help="strong mode: rows = bit rows of both roles sharded over the ranks (2, 4, 8 ranks), roles = one "
+                         "direction per GPU (2 ranks; auto picks it there: nothing of the expansion crosses the link)")
     ap.add_argument("--no-verify", action="store_true",
                     help="strong mode: skip the bit-for-bit check of the gathered MT words against a one-GPU context")
     args = ap.parse_args()
@@ -460,7 +552,12 @@ def main():
     import flute_amd as fa
     n = 1 << args.log2n
     if world > 1 and args.mode == "strong":
-        strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n)
+        if args.split == "roles" or (args.split == "auto" and world == 2):
+            if world != 2:
+                raise SystemExit("--split roles needs exactly 2 ranks")
+            roles_main(args, fa, fd, dist, torch, rank, local_rank, world, n)
+        else:
+            strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n)
         return
     eng = fa.Engine(n, device=local_rank)
     conf = eng.conf

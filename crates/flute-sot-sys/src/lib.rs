@@ -89,6 +89,7 @@ extern "C" {
     pub fn sot_sender_hash(ctx: *mut SotCtx, delta: *const c_void, msgs_out: *mut c_void) -> c_int;
     pub fn sot_receiver_hash(ctx: *mut SotCtx, msgs_out: *mut c_void, choice_words_out: *mut u64) -> c_int;
     pub fn sot_mt_bits(ctx: *mut SotCtx, delta: *const c_void, a_out: *mut u64, b_out: *mut u64, c_out: *mut u64) -> c_int;
+    pub fn sot_mt_role_bits_to_device(ctx: *mut SotCtx, role: c_int, delta: *const c_void, dst_device: *mut c_void, dst_bytes: u64) -> c_int;
     pub fn sot_mt_bits_to_device(ctx: *mut SotCtx, dst_device: *mut c_void, dst_bytes: u64) -> c_int;
     pub fn sot_ctx_create_sharded(n: u64, scaler: u64, device: c_int, rank: u32, world: u32, ggm_replicated: c_int, out: *mut *mut SotCtx) -> c_int;
     pub fn sot_shard_info_get(ctx: *const SotCtx, out: *mut SotShardInfo) -> c_int;

@@ -422,6 +422,18 @@ extern "C" int sot_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t 
     return hash_mt_bits(c, delta, a, b, cc);
 }
 
+extern "C" int sot_mt_role_bits_to_device(sot_ctx *c, int role, const void *delta, void *dst_device, uint64_t dst_bytes) {
+    CHECK_CTX(c);
+    if ((role != SOT_ROLE_SENDER && role != SOT_ROLE_RECEIVER) || (role == SOT_ROLE_SENDER && !delta)) return SOT_EINVAL;
+    const uint64_t bytes = 2 * ((c->n_out + 63) / 64) * 8;
+    if (!dst_device || dst_bytes < bytes) {
+        sot_set_error("mt_role_bits_to_device: destination of %llu bytes, need %llu", (unsigned long long)dst_bytes,
+                      (unsigned long long)bytes);
+        return SOT_EINVAL;
+    }
+    return hash_mt_role_bits(c, role, delta, (uint64_t *)dst_device);
+}
+
 extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_bytes) {
     CHECK_CTX(c);
     const uint64_t bytes = 3 * ((c->n_out + 63) / 64) * 8;

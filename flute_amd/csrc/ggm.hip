@@ -409,6 +409,40 @@ __global__ void k_mt_bits(const blk_t *__restrict__ B, const blk_t *__restrict__
     }
 }
 
+// The same bits by direction, for a party that runs its two directions on two GPUs (role split, shard.hip / dist.py): the
+// reference computes them on two thread pools and joins (gmw/src/mul_triple/silent_ot.rs:87-111). Sender direction:
+// b = lsb(m0) ^ lsb(m1), v = lsb(m0) of its own messages; receiver direction: a = lsb(A), u = lsb(H(A & ~1)); the join is
+// c = a & b ^ u ^ v, word-wise.
+__global__ void k_mt_role_bits(const blk_t *__restrict__ E, int sender, blk_t delta, uint64_t n, uint64_t *__restrict__ w0,
+                               uint64_t *__restrict__ w1) {
+    __shared__ uint32_t te[1][AES_LDS_WORDS];
+    aes_lds_fill(te);
+    blk_t d = delta;
+    d.x &= ~1u;
+    const uint64_t n_pad = (n + 63) & ~63ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t x0 = 0, x1 = 0;
+        if (i < n) {
+            blk_t m = E[i];
+            const uint32_t lsb = m.x & 1u;
+            m.x &= ~1u;
+            const uint32_t h0 = cr_hash(te, m).x & 1u;
+            if (sender) {
+                x0 = h0 ^ (cr_hash(te, bxor(m, d)).x & 1u);  // b
+                x1 = h0;                                      // v
+            } else {
+                x0 = lsb;  // a
+                x1 = h0;   // u
+            }
+        }
+        const unsigned long long b0 = __ballot(x0), b1 = __ballot(x1);
+        if ((threadIdx.x & 63) == 0) {
+            w0[i >> 6] = b0;
+            w1[i >> 6] = b1;
+        }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -663,6 +697,27 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
     if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_chw, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
+// dst_device: 2 * ceil(n_out / 64) words: b | v (sender) or a | u (receiver)
+int hash_mt_role_bits(sot_ctx *c, int role, const void *delta, uint64_t *dst_device) {
+    if (!c->role[role].encoded) {
+        sot_set_error("mt_role_bits: this direction is not encoded yet");
+        return SOT_ESTATE;
+    }
+    if (role == SOT_ROLE_RECEIVER && c->recv_unpacked) {
+        sot_set_error("mt_role_bits needs ChoiceBitPacking::True; the receiver's last encode was unpacked");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t nw = (c->n_out + 63) / 64;
+    blk_t d = make_uint4(0, 0, 0, 0);
+    if (role == SOT_ROLE_SENDER) memcpy(&d, delta, 16);
+    SOT_LAUNCH(c, KID_MT_BITS, k_mt_role_bits, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[role].enc,
+               role == SOT_ROLE_SENDER ? 1 : 0, d, c->n_out, dst_device, dst_device + nw);
+    SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }

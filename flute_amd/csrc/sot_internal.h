@@ -193,6 +193,7 @@ int ggm_upload_rT(sot_ctx *c, int role, const void *rT);
 int hash_sender(sot_ctx *c, const void *delta, void *msgs_out);
 int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out);
 int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64_t *cc);
+int hash_mt_role_bits(sot_ctx *c, int role, const void *delta, uint64_t *dst_device);
 int util_transpose128(int device, const void *in, void *out, uint64_t ntiles);
 int util_aes(int device, const void *key16, const void *in, void *out, uint64_t n, int cr_hash);
 int util_aes_ctr_device(sot_ctx *c, const uint8_t key16[16], uint64_t first, blk_t *d_out, uint64_t nblocks);

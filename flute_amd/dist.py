@@ -173,3 +173,61 @@ class ShardedPipeline:
         else:
             self.mt.zero_()
         return gather_sharded_words(self.mt, self.world) if gather else self.mt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two GPUs: one direction per GPU
+def join_role_words(flat, nw):
+    """flat: the all-gathered per-direction words of the two ranks, [b | v | a | u] (rank 0 = the sender direction's b, v;
+    rank 1 = the receiver direction's a, u; nw words each) -> [3, nw] a | b | c with c = a & b ^ u ^ v
+    (gmw/src/mul_triple/silent_ot.rs:93-111: the join of the two directions' bits)."""
+    import torch
+    b, v, a, u = flat[0:nw], flat[nw:2 * nw], flat[2 * nw:3 * nw], flat[3 * nw:4 * nw]
+    return torch.stack([a, b, (a & b) ^ u ^ v])
+
+
+class RoleSplitPipeline:
+    """A party's precompute_mts over TWO GPUs by direction: rank 0 runs the sender instance, rank 1 the receiver instance
+    -- the reference runs them concurrently on two thread pools (gmw/src/mul_triple/silent_ot.rs:47,87-91) -- each on an
+    ordinary one-GPU context (all trees, all 128 bit rows of its direction). Nothing of the expansion crosses the link:
+    each rank reduces its direction to two bit vectors (sot_mt_role_bits_to_device), one all-gather of 2 * n / 8 bytes per
+    rank puts both on both GPUs, and the join c = a & b ^ u ^ v is three word-wise tensor operations."""
+
+    def __init__(self, engine, rank, gather=None, torch_device=None):
+        import torch
+        self.eng, self.rank = engine, rank
+        dev = torch_device if torch_device is not None else torch.device("cuda", engine.device)
+        self.nw = (engine.n_out + 63) // 64
+        self.buf = torch.zeros(2 * self.nw, dtype=torch.int64, device=dev)
+        self.gather = gather or self._all_gather
+
+    def _all_gather(self, local):
+        import torch
+        import torch.distributed as dist
+        flat = torch.empty(2 * local.numel(), dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend() == "gloo":  # rehearsals of GPU ranks over gloo: staged through the host
+            h = torch.empty(flat.numel(), dtype=local.dtype)
+            dist.all_gather_into_tensor(h, local.cpu())
+            flat.copy_(h)
+        else:
+            dist.all_gather_into_tensor(flat, local)
+        return flat
+
+    def direction(self, sender_base, delta, seed, threads, recv_base, recv_choices, tg_sums, tg_last, points):
+        """this rank's direction up to its two bit vectors; rank 0 returns the sender's TreeGrps (for the peer party)"""
+        e = self.eng
+        tg = None
+        if self.rank == 0:
+            tg = e.sender_expand(sender_base, delta, seed, threads)
+            e.qc_encode(0)
+            e.mt_role_bits_to_device(0, delta, self.buf.data_ptr(), self.buf.numel() * 8)
+        else:
+            e.receiver_expand(recv_base, recv_choices, tg_sums, tg_last)
+            e.qc_encode(1, points)
+            e.mt_role_bits_to_device(1, None, self.buf.data_ptr(), self.buf.numel() * 8)
+        return tg
+
+    def join(self):
+        """-> [3, ceil(n / 64)] int64 a | b | c, the party's whole MT store, on both GPUs"""
+        return join_role_words(self.gather(self.buf), self.nw)
+

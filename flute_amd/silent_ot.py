@@ -262,6 +262,13 @@ class Engine:
         return a, b, c
 
 
+    def mt_role_bits_to_device(self, role, delta, device_ptr, nbytes):
+        """the MT bits of one direction (b | v for ROLE_SENDER, a | u for ROLE_RECEIVER; 2 * ceil(n / 64) words) into a
+        caller-owned device buffer: sot_mt_role_bits_to_device, role split over two GPUs"""
+        d = _blk(delta) if delta is not None else None
+        check(self.lib.sot_mt_role_bits_to_device(self.h, role, _p(d) if d is not None else None, C.c_void_p(device_ptr),
+                                                  nbytes))
+
     def mt_words(self):
         """3 * ceil(n / 64): length in u64 of the a | b | c buffer of mt_bits_to_device."""
         return 3 * ((self.n_out + 63) // 64)

@@ -129,6 +129,12 @@ int sot_receiver_hash(sot_ctx *ctx, void *msgs_out, uint64_t *choice_words_out);
  * NULL to leave the bits on the device only. */
 int sot_mt_bits(sot_ctx *ctx, const void *delta, uint64_t *a_out, uint64_t *b_out, uint64_t *c_out);
 
+/* The MT bits of ONE direction, for a party that runs its two directions on two GPUs (role split; the reference runs them
+ * on two thread pools and joins, gmw/src/mul_triple/silent_ot.rs:87-111). role = SOT_ROLE_SENDER: b | v with b = lsb(m0) ^
+ * lsb(m1), v = lsb(m0) of this direction's messages (delta required); SOT_ROLE_RECEIVER: a | u with a = the choice bit, u =
+ * the lsb of its message. 2 * ceil(n / 64) words into a caller-owned DEVICE buffer; the join on any GPU that holds both is
+ * a, b, c = a & b ^ u ^ v word by word (flute_amd/dist.py::RoleSplitPipeline gathers them with one RCCL all-gather). */
+int sot_mt_role_bits_to_device(sot_ctx *ctx, int role, const void *delta, void *dst_device, uint64_t dst_bytes);
 /* The three MT bit vectors of the last sot_mt_bits, a | b | c (3 * ceil(n/64) u64), copied device-to-device into a
  * caller-owned DEVICE buffer on the context's GPU (synchronous on return). No counterpart in the reference (its
  * MulTriples live in host memory, gmw/src/mul_triple/mod.rs:30-35): this is what a multi-GPU party hands to the

@@ -108,3 +108,40 @@ def test_two_rank_strong_scaling_collectives():
     for rank, ok, g in res:
         assert ok, "all-to-all delivered the wrong messages on rank %d" % rank
         assert g == want.tobytes()
+
+
+def _worker_roles(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    from flute_amd import dist as fd
+    d = fd.init("gloo", rank, world)
+    nw = 7
+    words = np.random.default_rng(5).integers(-2 ** 63, 2 ** 63, (4, nw), dtype=np.int64)  # b, v, a, u
+    local = torch.from_numpy(np.concatenate([words[2 * rank], words[2 * rank + 1]]))
+
+    class _Eng:  # RoleSplitPipeline only needs n_out and device from the engine for its buffers
+        n_out, device = 64 * nw, 0
+    pipe = fd.RoleSplitPipeline(_Eng(), rank, torch_device=torch.device("cpu"))
+    pipe.buf.copy_(local)
+    got = pipe.join().numpy()
+    q.put((rank, got.tobytes()))
+    d.destroy_process_group()
+
+
+def test_two_rank_role_split_join():
+    """RoleSplitPipeline.join over gloo, world size 2: all-gather of the two directions' bit vectors and c = a & b ^ u ^ v"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_roles, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    b, v, a, u = np.random.default_rng(5).integers(-2 ** 63, 2 ** 63, (4, 7), dtype=np.int64)
+    want = np.stack([a, b, (a & b) ^ u ^ v]).tobytes()
+    assert res[0][1] == want and res[1][1] == want

@@ -150,3 +150,43 @@ def test_sharded_context_refuses_whole_matrix_stages(fa):
         fa.ShardedEngine(1000, 0, 3)
     with pytest.raises(SotError):
         fa.ShardedEngine(1000, 2, 2)
+
+
+@pytest.mark.parametrize("n,T", [(1000, 2), (100003, 3), (1 << 20, 4)])
+def test_role_split_equals_one_gpu(fa, n, T):
+    """two GPUs by direction (flute_amd/dist.py::RoleSplitPipeline, sot_mt_role_bits_to_device): the sender instance on
+    one context, the receiver instance on another, joined from their bit vectors = the MT words of one context"""
+    import torch
+    from flute_amd import dist as fd
+    rng = np.random.default_rng(n)
+    ref = fa.Engine(n)
+    conf = ref.conf
+    x = fa.fake_base(conf, rng)
+    y = fa.fake_base(conf, rng)
+    delta, seed, delta_peer, seed_peer = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    try:
+        tg_y = ref.sender_expand(y[0], delta_peer, seed_peer, T)
+        tg_x = ref.sender_expand(x[0], delta, seed, T)
+        ref.qc_encode(0)
+        ref.receiver_expand(y[1], y[2], *tg_y)
+        pts = ref.points(y[2])
+        ref.qc_encode(1, pts)
+        want = np.stack(ref.mt_bits(delta))
+    finally:
+        ref.close()
+    engs = [fa.Engine(n), fa.Engine(n)]
+    try:
+        pipes = [fd.RoleSplitPipeline(e, r, gather=lambda local: None) for r, e in enumerate(engs)]
+        tg = pipes[0].direction(x[0], delta, seed, T, y[1], y[2], tg_y[0], tg_y[1], pts)
+        assert np.array_equal(tg[0], tg_x[0]) and np.array_equal(tg[1], tg_x[1])
+        assert pipes[1].direction(x[0], delta, seed, T, y[1], y[2], tg_y[0], tg_y[1], pts) is None
+        torch.cuda.synchronize()
+        flat = torch.cat([pipes[0].buf, pipes[1].buf])  # what the all-gather leaves on both ranks
+        got = fd.join_role_words(flat, pipes[0].nw).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want)
+        from flute_amd.lib import SotError
+        with pytest.raises(SotError):  # the receiver direction was never encoded on context 0
+            engs[0].mt_role_bits_to_device(1, None, pipes[0].buf.data_ptr(), pipes[0].buf.numel() * 8)
+    finally:
+        for e in engs:
+            e.close()

@@ -62,6 +62,28 @@ def main():
         eng.close()
         del pipe
         torch.cuda.empty_cache()
+    # two GPUs by direction (RoleSplitPipeline): each rank's whole step on an ordinary context
+    eng = fa.Engine(n, device=0)
+    conf = eng.conf
+    rng = np.random.default_rng(1)
+    x = fa.fake_base(conf, rng)
+    y = fa.fake_base(conf, rng)
+    delta, seed, delta_peer, seed_peer = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
+    tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, 4)
+    pts = eng.points(y[2])
+    out["roles"] = []
+    for rank in (0, 1):
+        pipe = fd.RoleSplitPipeline(eng, rank, gather=lambda local: None)
+        pipe.direction(x[0], delta, seed, 4, y[1], y[2], tg_y[0], tg_y[1], pts)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pipe.direction(x[0], delta, seed, 4, y[1], y[2], tg_y[0], tg_y[1], pts)
+        eng.sync()
+        out["roles"].append({"rank": rank, "direction": "sender" if rank == 0 else "receiver",
+                             "compute_ms_per_step": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                             "all_gather_bytes_per_rank": int(pipe.buf.numel() * 8)})
+    eng.close()
     print(json.dumps(out))
 
 
