@@ -1050,14 +1050,30 @@ __device__ __forceinline__ typename tile_regs<(1 << NB) / TL_WAVES>::type tile_f
     const uint32_t *__restrict__ Z, const tile_desc &d, uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
     constexpr int PER = (1 << NB) / TL_WAVES;
     const uint32_t nslots = 1u << d.nb;
-    const uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+    // wave-uniform base (scalar registers) + one 32-bit per-lane byte offset shared by all PER loads: per-lane 64-bit
+    // addresses for 32 granules in flight cost 64 VGPRs and spilled (k_top<.,9>: 13-16 VGPRs in scratch). Z < 4 GiB.
+    const uint32_t voff = (((base_w | tile_word(d, wave)) * ROWS) + rh * TL_ROWS + lane) * 4u;
+    // the granule offsets tile_word(d, 16 i) are loop invariants of the persistent kernels: hoisted, they (and those of
+    // tile_store) sit in 128 SGPRs and spill into VGPR lanes. An opaque copy of the position word keeps them inside the
+    // loop, rebuilt from five basis offsets (tile bits 4..8) with a few scalar ORs each.
+    uint64_t pq = d.posq;
+    asm volatile("" : "+s"(pq));
+    uint32_t basis[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) basis[j] = 1u << ((uint32_t)(pq >> (5 * (4 + j))) & 31u);
     typename tile_regs<PER>::type v;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const uint32_t s = wave + TL_WAVES * i;
         uint32_t x = 0;
-        if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u)))
-            x = g[(uint64_t)tile_word(d, TL_WAVES * i) * ROWS];
+        if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u))) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+                if ((i >> j) & 1) w |= basis[j];
+            const char *ub = (const char *)Z + (uint64_t)w * (ROWS * 4);
+            x = *(const uint32_t *)(ub + voff);
+        }
         v[i] = x;
     }
     return v;
@@ -1077,12 +1093,24 @@ template <int NB, int WAVES = TL_WAVES>
 __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__restrict__ Z, const tile_desc &d,
                                            uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
     constexpr int PER = (1 << NB) / WAVES;
+    constexpr int LWV = WAVES == 16 ? 4 : WAVES == 8 ? 3 : WAVES == 4 ? 2 : WAVES == 2 ? 1 : 0;
     const uint32_t nslots = 1u << d.nb;
-    uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+    const uint32_t voff = (((base_w | tile_word(d, wave)) * ROWS) + rh * TL_ROWS + lane) * 4u;
+    uint64_t pq = d.posq;  // see tile_fetch
+    asm volatile("" : "+s"(pq));
+    uint32_t basis[9];
+#pragma unroll
+    for (int j = 0; j < 9 - LWV; j++) basis[j] = 1u << ((uint32_t)(pq >> (5 * (LWV + j))) & 31u);
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const uint32_t s = wave + WAVES * i;
-        if (s < nslots) g[(uint64_t)tile_word(d, WAVES * i) * ROWS] = lds[s * TL_ROWS + lane];
+        if (s < nslots) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 9 - LWV; j++)
+                if ((i >> j) & 1) w |= basis[j];
+            *(uint32_t *)((char *)Z + (uint64_t)w * (ROWS * 4) + voff) = lds[s * TL_ROWS + lane];
+        }
     }
 }
 
