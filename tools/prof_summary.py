@@ -86,7 +86,7 @@ def main():
         # stage totals. The profiled command is bench.py: every QC encode ends in one k_qc_finish launch, so
         # launches // encodes = launches of a kernel per encode (the transforms of the public polynomial at context
         # creation add fewer than one per encode); the GGM kernels run once per expansion = per encode.
-        enc = pmc.get("k_qc_finish", {}).get("launches", 0)
+        enc = next((e["launches"] for k, e in pmc.items() if k.startswith("k_qc_finish")), 0)
         if enc:
             tot = {"fetch": 0.0, "write": 0.0}
             per_kernel = {}
