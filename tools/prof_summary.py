@@ -23,7 +23,11 @@ def short(name):
 # 128-B requests. Calibrated on this repository's own access patterns with tools/micro/gather_copy.hip under
 # rocprofv3 --pmc FETCH_SIZE (512 MiB read once): 256 B per wave instruction (4 B/lane) -> 262 320 KiB = 1/2; 128-B pieces
 # (8 lanes x 16 B) -> 262 152 KiB = 1/2; 64-B pieces (4 lanes x 16 B, the 16-row tiles) -> 524 298 KiB = exact.
-FETCH_FACTOR_EXACT = ("k_conv_unit", "k_conv_tile")  # 16-row tiles: 64-B pieces
+# The last case no longer occurs in the product: with the XCD-aware slice order the pieces of a line are requested by
+# workgroups of one XCD at about the same time and leave its L2 as whole 128-B requests -- k_conv_unit<true> reads
+# 537 MB and the counter shows 277 MB (profiles/r2_e_pmc.csv), i.e. 1/2 again. (k_conv_tile, the fallback for
+# SOT_NO_TOP, keeps the old order.)
+FETCH_FACTOR_EXACT = ("k_conv_tile",)
 QC_PREFIXES = ("k_qc_load", "k_conv_", "k_top", "k_mid", "k_fft_low<1", "k_tile_fft", "k_qc_finish", "k_clear_lsb",
                "k_sparse_choice", "k_set_points")
 GGM_PREFIXES = ("k_roots", "k_ggm_", "k_sender_treegrp", "k_recv_")
