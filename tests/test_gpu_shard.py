@@ -95,7 +95,10 @@ def _run_sharded(fa, n, T, world, replicated, x, y, tg_y, delta, seed):
 
 CASES = [(1000, 2, 2, False), (1000, 2, 4, False), (1000, 2, 8, False), (1000, 1, 2, True), (1000, 3, 8, True),
          (40000, 4, 4, False), (65536, 5, 8, False), (129, 3, 2, False), (1 << 20, 4, 2, False), (1 << 20, 4, 8, False),
-         (1 << 20, 4, 4, True), (3 * 2 ** 20 + 12345, 7, 4, False)]
+         (1 << 20, 4, 4, True), (3 * 2 ** 20 + 12345, 7, 4, False),
+         # the row-half / slice skipping of 4 and 8 ranks on every low-kernel template (m = 22 ... 24) and a ragged size
+         (100003, 3, 8, True), (1 << 21, 4, 4, False), (1 << 22, 4, 8, False), (1 << 23, 4, 4, False),
+         (3 * 2 ** 20 + 12345, 5, 8, False)]
 
 
 @pytest.mark.parametrize("n,T,world,replicated", CASES)
