@@ -35,6 +35,11 @@ struct sot_and_circ {
     uint32_t *xpos = nullptr, *ypos = nullptr;  // device: operand bit positions per gate
     uint64_t *vals = nullptr;                   // device
     uint64_t *d_own = nullptr, *e_own = nullptr, *d_peer = nullptr, *e_peer = nullptr;  // device, msg_words each
+    // sot_lut_online_eval: device scratch kept across calls (tables of the template; per-item arrays, grown on demand)
+    void *le_tab = nullptr;
+    uint64_t le_tab_bytes = 0;
+    uint8_t *le_items = nullptr;  // masked_in | lam_out | out, le_cap bytes each
+    uint64_t le_cap = 0;
 };
 
 __device__ __forceinline__ uint32_t bit_at(const uint64_t *__restrict__ w, uint64_t i) {
@@ -168,7 +173,7 @@ extern "C" int sot_and_circ_create(sot_ctx *c, uint32_t n_inputs, uint32_t n_gat
 extern "C" void sot_and_circ_destroy(sot_and_circ *q) {
     if (!q) return;
     (void)hipSetDevice(q->device);
-    void *ptrs[] = {q->xpos, q->ypos, q->vals, q->d_own, q->e_own, q->d_peer, q->e_peer};
+    void *ptrs[] = {q->xpos, q->ypos, q->vals, q->d_own, q->e_own, q->d_peer, q->e_peer, q->le_tab, q->le_items};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete q;
@@ -381,24 +386,19 @@ __global__ void __launch_bounds__(256)
     out[idx] = (uint8_t)((acc ^ lam_out[idx]) & 1u);
 }
 
-// host/device scratch of one call, freed on every path
-struct le_bufs {
-    void *p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int n = 0;
-    int up(void **out, const void *src, uint64_t bytes, hipStream_t st) {
-        *out = nullptr;
-        if (hipMalloc(out, bytes ? bytes : 16) != hipSuccess) {
-            sot_set_error("lut_online: hipMalloc(%llu bytes) failed", (unsigned long long)bytes);
-            return SOT_ENOMEM;
-        }
-        p[n++] = *out;
-        if (src && bytes) SOT_HIP(hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, st));
-        return SOT_OK;
+// grows a device buffer kept in the circuit (no allocation once it is large enough)
+static int le_reserve(void **buf, uint64_t *cap, uint64_t bytes) {
+    if (*cap >= bytes && *buf) return SOT_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr, *cap = 0;
+    if (hipMalloc(buf, bytes ? bytes : 16) != hipSuccess) {
+        (void)hipGetLastError();
+        sot_set_error("lut_online: hipMalloc(%llu bytes) failed", (unsigned long long)bytes);
+        return SOT_ENOMEM;
     }
-    ~le_bufs() {
-        for (int i = 0; i < n; i++) (void)hipFree(p[i]);
-    }
-};
+    *cap = bytes;
+    return SOT_OK;
+}
 
 extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
                                    const uint32_t *arity,
@@ -443,18 +443,32 @@ extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uin
     }
     SOT_HIP(hipSetDevice(c->device));
     const uint64_t items = (uint64_t)batch * n_luts;
-    le_bufs b;
-    uint32_t *d_ar, *d_tt, *d_ls, *d_tc;
-    uint64_t *d_lb;
-    uint8_t *d_m, *d_lo, *d_out;
-    SOT_TRY(b.up((void **)&d_ar, arity, (uint64_t)n_luts * 4, c->stream));
-    SOT_TRY(b.up((void **)&d_tt, tt, (uint64_t)n_luts * 32, c->stream));
-    SOT_TRY(b.up((void **)&d_ls, lsrc, (uint64_t)n_luts * 1024, c->stream));
-    SOT_TRY(b.up((void **)&d_tc, tcount, (uint64_t)q->n_layers * 4, c->stream));
-    SOT_TRY(b.up((void **)&d_lb, q->base.data(), (uint64_t)q->n_layers * 8, c->stream));
-    SOT_TRY(b.up((void **)&d_m, masked_in, items, c->stream));
-    SOT_TRY(b.up((void **)&d_lo, lam_out, items, c->stream));
-    SOT_TRY(b.up((void **)&d_out, nullptr, items, c->stream));
+    // tables: arity | tt | lsrc | tcount | layer bases, 8-byte aligned pieces in one buffer; items: three byte arrays
+    const uint64_t o_ar = 0, o_tt = o_ar + (((uint64_t)n_luts * 4 + 7) & ~7ull), o_ls = o_tt + (uint64_t)n_luts * 32;
+    const uint64_t o_tc = o_ls + (uint64_t)n_luts * 1024, o_lb = o_tc + (((uint64_t)q->n_layers * 4 + 7) & ~7ull);
+    const uint64_t tab_bytes = o_lb + (uint64_t)q->n_layers * 8 + 8;
+    SOT_TRY(le_reserve(&q->le_tab, &q->le_tab_bytes, tab_bytes));
+    if (q->le_cap < items) {  // three byte arrays of le_cap entries each
+        uint64_t got = 0;
+        void *p = q->le_items;
+        q->le_items = nullptr, q->le_cap = 0;
+        SOT_TRY(le_reserve(&p, &got, 3 * items));
+        q->le_items = (uint8_t *)p, q->le_cap = items;
+    }
+    char *tb = (char *)q->le_tab;
+    uint32_t *d_ar = (uint32_t *)(tb + o_ar), *d_tt = (uint32_t *)(tb + o_tt), *d_ls = (uint32_t *)(tb + o_ls);
+    uint32_t *d_tc = (uint32_t *)(tb + o_tc);
+    uint64_t *d_lb = (uint64_t *)(tb + o_lb);
+    uint8_t *d_m = q->le_items, *d_lo = q->le_items + q->le_cap, *d_out = q->le_items + 2 * q->le_cap;
+    SOT_HIP(hipMemcpyAsync(d_ar, arity, (uint64_t)n_luts * 4, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(d_tt, tt, (uint64_t)n_luts * 32, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(d_ls, lsrc, (uint64_t)n_luts * 1024, hipMemcpyHostToDevice, c->stream));
+    if (q->n_layers) {
+        SOT_HIP(hipMemcpyAsync(d_tc, tcount, (uint64_t)q->n_layers * 4, hipMemcpyHostToDevice, c->stream));
+        SOT_HIP(hipMemcpyAsync(d_lb, q->base.data(), (uint64_t)q->n_layers * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    SOT_HIP(hipMemcpyAsync(d_m, masked_in, items, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(d_lo, lam_out, items, hipMemcpyHostToDevice, c->stream));
     const uint64_t grid = (items + 255) / 256;
     hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, first_instance, batch, n_luts, n_in, d_ar, d_tt,
                        d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);

@@ -166,7 +166,9 @@ class ShardedPipeline:
         nwl = (self.eng.n_out + 63) // 64
         if nwl:
             import torch
-            tmp = torch.empty(3 * nwl, dtype=torch.int64, device=self.mt.device)
+            if getattr(self, "_tmp", None) is None or self._tmp.numel() != 3 * nwl:
+                self._tmp = torch.empty(3 * nwl, dtype=torch.int64, device=self.mt.device)  # once: no per-step allocation
+            tmp = self._tmp
             self.eng.mt_bits_to_device(tmp.data_ptr(), 3 * nwl * 8)
             self.mt.zero_()
             self.mt[:, :nwl] = tmp.reshape(3, nwl)
@@ -204,7 +206,9 @@ class RoleSplitPipeline:
     def _all_gather(self, local):
         import torch
         import torch.distributed as dist
-        flat = torch.empty(2 * local.numel(), dtype=local.dtype, device=local.device)
+        if getattr(self, "_flat", None) is None:
+            self._flat = torch.empty(2 * local.numel(), dtype=local.dtype, device=local.device)  # once
+        flat = self._flat
         if local.is_cuda and dist.get_backend() == "gloo":  # rehearsals of GPU ranks over gloo: staged through the host
             h = torch.empty(flat.numel(), dtype=local.dtype)
             dist.all_gather_into_tensor(h, local.cpu())
