@@ -34,8 +34,8 @@
 #ifndef QC_MIDMASK_LDS
 #define QC_MIDMASK_LDS 1  // k_mid: level masks through the wave's own LDS slots (1) or through the scalar unit (0)
 #endif
-#ifndef QC_LOWMASK_LDS
-#define QC_LOWMASK_LDS 1  // k_fft_low<1>: intra-word masks through LDS (1) or through the scalar unit (0)
+#ifndef LOW_RING
+#define LOW_RING 5  // k_fft_low: mask blocks (1.5 KiB) in a value word's 8 KiB ring, LOW_RING - 1 of them loaded ahead
 #endif
 
 static __device__ const uint32_t d_BETA[32] = {
@@ -1422,36 +1422,23 @@ __device__ __forceinline__ void mask_prefetch(uint32_t &pf, const uint32_t *a) {
 }
 __device__ __forceinline__ void mask_prefetch_drain(uint32_t &pf) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf)::"memory"); }
 
-template <int I, bool INV>
-__device__ __forceinline__ void low_level(uint32_t W[32], const uint32_t *LMi) {
-    const uint32_t A = lowmask(I);
-    constexpr int SH = 1 << I;
-    if (INV) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
-    }
-    uint32_t P[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) P[j] = BFI(W[j] >> SH, W[j + 16], A);
-    uint32_t acc[32];
-    apply_masks<16>(acc, P, LMi);
-#pragma unroll
-    for (int k = 0; k < 32; k++) W[k] = XAND(W[k], acc[k] ^ (acc[k] >> SH), A);
-    if (!INV) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
-    }
-}
-
-// The same level with its 16 x 32 masks read from LDS (M: 128 uint4, row j = M[8 j .. 8 j + 7]) as VGPR operands:
-// no scalar-memory stream, whose two rows in flight cannot cover the latency of a table that does not fit any cache.
+// One intra-word level with its masks read from LDS as VGPR operands (ds_read_b128, same address in every lane): no
+// scalar-memory stream, whose two rows in flight cannot cover the latency of a table that does not fit any cache.
+// The LDS pipe delivers one such read per ~5 cycles and CU, i.e. the level is bound by the NUMBER of mask words, so the
+// 32 x 32 twiddle matrix of a position is applied Karatsuba-style over the tower GF(2^32) = GF(2^16)[t], t^2 = t + zeta:
+// in blocks of 16 planes it is [[A, X], [B, A + B]], hence with y = (y_lo, y_hi), s = y_lo + y_hi
+//     out_lo = A y_lo + X y_hi                    (set 1: 16 x 16 mask words, y_lo at the x positions, y_hi at the y positions)
+//     out_hi = (A + B) s + A y_lo                 (set 2:  8 x 16 mask words, s_j at the x positions, s_(j+8) at the y positions)
+// 384 mask words per (value word, level) instead of 512 (k_build_lowmasks), + ~90 plain VALU ops that the LDS bound hides.
+#define LOW_BLK_WORDS 384  // 96 uint4: set 1 = M[4 j + kq], j < 16; set 2 = M[64 + 4 j' + kq], j' < 8
+#define AMAT_WORDS 768     // per value word: A[16][16] | X[16][16] | (A+B)[16][16] of the FFT(a) values (k_build_amat)
 template <int NJ>
-__device__ __forceinline__ void apply_masks_lds(uint32_t acc[32], const uint32_t v[NJ], const uint4 *M) {
+__device__ __forceinline__ void apply_masks16_lds(uint32_t acc[16], const uint32_t *v, const uint4 *M) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
 #pragma unroll
-        for (int kq = 0; kq < 8; kq++) {
-            const uint4 m = M[j * 8 + kq];
+        for (int kq = 0; kq < 4; kq++) {
+            const uint4 m = M[j * 4 + kq];
             acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
             acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
             acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
@@ -1467,19 +1454,46 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
     }
-    uint32_t P[16];
+    uint32_t P[16];  // y_j at the x positions, y_(j+16) at the y positions
 #pragma unroll
     for (int j = 0; j < 16; j++) P[j] = BFI(W[j] >> SH, W[j + 16], A);
-    uint32_t acc[32];
+    uint32_t a1[16];
 #pragma unroll
-    for (int k = 0; k < 32; k++) acc[k] = 0;
-    apply_masks_lds<16>(acc, P, M);
+    for (int k = 0; k < 16; k++) a1[k] = 0;
+    apply_masks16_lds<16>(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
+    uint32_t S[8];
 #pragma unroll
-    for (int k = 0; k < 32; k++) W[k] = XAND(W[k], acc[k] ^ (acc[k] >> SH), A);
+    for (int j = 0; j < 8; j++) S[j] = BFI(P[j] ^ (P[j] >> SH), P[j + 8] ^ (P[j + 8] << SH), A);
+    uint32_t a3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a3[k] = 0;
+    apply_masks16_lds<8>(a3, S, M + 64);  // x + y positions: (A + B) s
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        W[k] = XAND(W[k], a1[k] ^ (a1[k] >> SH), A);
+        W[k + 16] = XAND(W[k + 16], a3[k] ^ (a3[k] >> SH) ^ a1[k], A);
+    }
     if (!INV) {
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] ^= (W[k] & A) << SH;
     }
+}
+// pointwise multiply by FFT(a), same decomposition, the 768 mask words of a value word as two blocks of 384:
+// block 0 = A | X[0..7], block 1 = X[8..15] | (A + B)
+__device__ __forceinline__ void amat_block0(const uint32_t W[32], const uint4 *M, uint32_t t1[16], uint32_t t2[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) t1[k] = 0, t2[k] = 0;
+    apply_masks16_lds<16>(t1, W, M);
+    apply_masks16_lds<8>(t2, W + 16, M + 64);
+}
+__device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, const uint32_t t1[16], uint32_t t2[16]) {
+    apply_masks16_lds<8>(t2, W + 24, M);
+    uint32_t sm[16], t3[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[j] = W[j] ^ W[j + 16], t3[j] = 0;
+    apply_masks16_lds<16>(t3, sm, M + 32);
+#pragma unroll
+    for (int k = 0; k < 16; k++) W[k] = t1[k] ^ t2[k], W[k + 16] = t3[k] ^ t1[k];
 }
 // mask blocks of a value word in the order the fused kernel consumes them (2 KiB each): forward levels 4..0, the two
 // halves of Amat, inverse levels 0..4. Word offset into LM (levels) or Amat.
@@ -1883,99 +1897,54 @@ __global__ void __launch_bounds__(64 * NVW)
     }
     const uint32_t base_w = tile_base(d, o);
     const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
-    // first mask lines of this wave's value word (see mask_prefetch); issued before the tile's own loads, so they
-    // are older than every load the compiler tracks
-    uint32_t pf = 0;
-    if (wave < nvw && !(MODE == 1 && QC_LOWMASK_LDS))
-        mask_prefetch(pf, LM + ((uint64_t)o * nvw + wave) * (5 * 512) + 3 * 512 + lane * 16);  // levels 3, 4
     tile_load<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
     __syncthreads();
     if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
     for (uint32_t vi = wave; vi < nvw; vi += NVW) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
         const uint64_t vw = (uint64_t)o * nvw + vi;  // wave-uniform
-        const uint32_t *L = LM + vw * (5 * 512);
-        const uint32_t *A = Amat + vw * 1024;
-        // The 14 KiB of masks of this value word are streamed once through the scalar unit, two 128-B rows in
-        // flight: far too little to cover an HBM miss. Vector loads that touch the lines ahead of time (one lane
-        // per 64-B line, result unused) pull them into L2 one to two levels before the scalar loads arrive.
-        if (MODE == 1 && QC_LOWMASK_LDS) {
-            // While W is in registers the 8 KiB of this value word in LDS are free and private to the wave: a ring of
-            // four 2 KiB mask blocks, filled three blocks ahead with plain vector loads (2 x 16 B per lane and block).
-            uint4 *R = (uint4 *)(lds + (vi << 5) * TL_ROWS);
-            auto src = [&](int b) {
-                return (const uint4 *)(lowblk_is_amat(b) ? A + (b - 5) * 512 : L + lowblk_level(b) * 512) + lane;
-            };
-            uint4 s0[3], s1[3];
+        const uint32_t *L = LM + vw * (5 * LOW_BLK_WORDS);
+        const uint32_t *A = Amat + vw * AMAT_WORDS;
+        // While W is in registers the 8 KiB of this value word in LDS are free and private to the wave: a ring of
+        // LOW_RING mask blocks of 1.5 KiB, filled LOW_RING - 1 blocks ahead with plain vector loads (16 B per lane, and
+        // 16 B more in the lower half of the wave, per block). Blocks in the order they are consumed: forward levels
+        // 4..0, [the two blocks of Amat, inverse levels 0..4].
+        constexpr int NBLK = MODE == 1 ? 12 : 5, AH = LOW_RING - 1;
+        uint4 *R = (uint4 *)(lds + (vi << 5) * TL_ROWS);
+        const uint32_t l2 = 64 + (lane & 31);
+        auto src = [&](int b) {
+            return (const uint4 *)(lowblk_is_amat(b) ? A + (b - 5) * LOW_BLK_WORDS : L + lowblk_level(b) * LOW_BLK_WORDS);
+        };
+        uint4 s0[AH], s1[AH];
 #pragma unroll
-            for (int b = 0; b < 3; b++) s0[b] = src(b)[0], s1[b] = src(b)[64];
-            uint32_t W[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
-#pragma unroll
-            for (int b = 0; b < 3; b++) R[b * 128 + lane] = s0[b], R[b * 128 + 64 + lane] = s1[b];
-            uint32_t t[32];
-#pragma unroll
-            for (int b = 0; b < 12; b++) {
-                uint4 n0, n1;
-                if (b + 3 < 12) n0 = src(b + 3)[0], n1 = src(b + 3)[64];
-                const uint4 *M = R + (b & 3) * 128;
-                switch (b) {
-                    case 0: low_level_lds<4, false>(W, M); break;
-                    case 1: low_level_lds<3, false>(W, M); break;
-                    case 2: low_level_lds<2, false>(W, M); break;
-                    case 3: low_level_lds<1, false>(W, M); break;
-                    case 4: low_level_lds<0, false>(W, M); break;
-                    case 5:
-#pragma unroll
-                        for (int k = 0; k < 32; k++) t[k] = 0;
-                        apply_masks_lds<16>(t, W, M);
-                        break;
-                    case 6:
-                        apply_masks_lds<16>(t, W + 16, M);
-#pragma unroll
-                        for (int k = 0; k < 32; k++) W[k] = t[k];
-                        break;
-                    case 7: low_level_lds<0, true>(W, M); break;
-                    case 8: low_level_lds<1, true>(W, M); break;
-                    case 9: low_level_lds<2, true>(W, M); break;
-                    case 10: low_level_lds<3, true>(W, M); break;
-                    default: low_level_lds<4, true>(W, M); break;
-                }
-                if (b + 3 < 12) R[((b + 3) & 3) * 128 + lane] = n0, R[((b + 3) & 3) * 128 + 64 + lane] = n1;
-            }
-#pragma unroll
-            for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
-            continue;
-        }
-        const uint32_t l16 = lane * 16, h16 = (lane & 31) * 16;
-        if (vi != wave) mask_prefetch(pf, L + 3 * 512 + l16);  // levels 3, 4
+        for (int b = 0; b < AH; b++) s0[b] = src(b)[lane], s1[b] = src(b)[l2];
         uint32_t W[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
-        mask_prefetch(pf, L + 1 * 512 + l16);  // levels 1, 2
-        low_level<4, false>(W, L + 4 * 512);
-        low_level<3, false>(W, L + 3 * 512);
-        mask_prefetch(pf, (lane < 32 || MODE == 0 ? L : A) + h16);  // level 0 | first half of Amat
-        low_level<2, false>(W, L + 2 * 512);
-        if (MODE == 1) mask_prefetch(pf, A + 512 + h16);  // second half of Amat
-        low_level<1, false>(W, L + 1 * 512);
-        low_level<0, false>(W, L);
-        if (MODE == 1) {
-            uint32_t t[32];
-            mask_prefetch(pf, L + l16);  // levels 0, 1 again (the inverse levels)
-            apply_masks<32>(t, W, A);    // Amat[value word][j][k]
 #pragma unroll
-            for (int k = 0; k < 32; k++) W[k] = t[k];
-            mask_prefetch(pf, L + 2 * 512 + l16);  // levels 2, 3
-            low_level<0, true>(W, L);
-            low_level<1, true>(W, L + 1 * 512);
-            mask_prefetch(pf, L + 4 * 512 + h16);  // level 4
-            low_level<2, true>(W, L + 2 * 512);
-            low_level<3, true>(W, L + 3 * 512);
-            low_level<4, true>(W, L + 4 * 512);
+        for (int b = 0; b < AH; b++) R[b * 96 + lane] = s0[b], R[b * 96 + l2] = s1[b];
+        uint32_t t1[16], t2[16];
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            uint4 n0, n1;
+            if (b + AH < NBLK) n0 = src(b + AH)[lane], n1 = src(b + AH)[l2];
+            const uint4 *M = R + (b % LOW_RING) * 96;
+            switch (b) {
+                case 0: low_level_lds<4, false>(W, M); break;
+                case 1: low_level_lds<3, false>(W, M); break;
+                case 2: low_level_lds<2, false>(W, M); break;
+                case 3: low_level_lds<1, false>(W, M); break;
+                case 4: low_level_lds<0, false>(W, M); break;
+                case 5: amat_block0(W, M, t1, t2); break;
+                case 6: amat_block1(W, M, t1, t2); break;
+                case 7: low_level_lds<0, true>(W, M); break;
+                case 8: low_level_lds<1, true>(W, M); break;
+                case 9: low_level_lds<2, true>(W, M); break;
+                case 10: low_level_lds<3, true>(W, M); break;
+                default: low_level_lds<4, true>(W, M); break;
+            }
+            if (b + AH < NBLK) R[((b + AH) % LOW_RING) * 96 + lane] = n0, R[((b + AH) % LOW_RING) * 96 + l2] = n1;
         }
-        mask_prefetch_drain(pf);
 #pragma unroll
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
     }
@@ -1996,13 +1965,18 @@ static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
     }
 }
 
-// LM[((value word * 5 + i) * 16 + j) * 32 + k]: the packed twiddle masks of intra-word level i (see low_level)
+// LM[(value word * 5 + i) * 384 + t]: the packed twiddle masks of intra-word level i (see low_level_lds). Bit p of a
+// mask belongs to the pair whose x position is p with bit i cleared; R = row of that pair's twiddle matrix.
+//   t < 256:  j = t / 16, k = t % 16: bit j of row k at x positions (A), bit j + 16 at y positions (X)
+//   t >= 256: j' = (t - 256) / 16, k: bit 16 + j' of row k + 16 at x positions, bit 24 + j' at y positions (A + B)
 __global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__restrict__ TW, uint32_t *__restrict__ LM) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nvals * 5 * 512) return;
-    const uint32_t k = idx & 31, j = (idx >> 5) & 15;
-    const uint32_t li = (uint32_t)((idx >> 9) % 5);
-    const uint32_t vw = (uint32_t)(idx / (5 * 512));
+    if (idx >= nvals * 5 * LOW_BLK_WORDS) return;
+    const uint32_t t = (uint32_t)(idx % LOW_BLK_WORDS);
+    const uint32_t li = (uint32_t)((idx / LOW_BLK_WORDS) % 5);
+    const uint32_t vw = (uint32_t)(idx / (5 * LOW_BLK_WORDS));
+    const bool set2 = t >= 256;
+    const uint32_t j = set2 ? (t - 256) >> 4 : t >> 4, k = (t & 15) + (set2 ? 16 : 0);
     const uint32_t nvw = 1u << (d.nb - 5);
     const uint32_t w = tile_base(d, vw / nvw) | tile_word(d, (vw % nvw) << 5);
     const uint32_t q = ((1u << d.m) | ((w & ~d.pmw) << 5)) >> li;
@@ -2012,23 +1986,27 @@ __global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__
     for (uint32_t p = 0; p < 32; p++) {
         const uint32_t e = (p & ~(1u << li)) >> li;  // per-position twiddle index of the pair's x position
         const uint32_t R = rw[0] ^ TW[(e << 5) + k];
-        const uint32_t jj = ((p >> li) & 1u) ? j + 16 : j;
+        const uint32_t ypos = (p >> li) & 1u;
+        const uint32_t jj = set2 ? 16 + j + 8 * ypos : j + 16 * ypos;
         mask |= ((R >> jj) & 1u) << p;
     }
     LM[idx] = mask;
 }
 
-// Amat[(o * nvw + vi)][j][k] bit p = bit k of (FFT(a) value at position p of value word (o, vi)) (x) 2^j; row 0 of Z
+// Amat[(o * nvw + vi) * 768 + t] bit p = entry (k, j) of the matrix 'multiply by the FFT(a) value at position p of value
+// word (o, vi)' (bit k of value (x) 2^j; row 0 of Z): t < 256: (k, j) = (t % 16, t / 16); 256 <= t < 512:
+// (t % 16, 16 + (t - 256) / 16); t >= 512: (16 + t % 16, 16 + (t - 512) / 16). See amat_block0/1.
 __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64_t nvals, uint32_t *__restrict__ Amat) {
-    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (value word, k, j)
-    if (idx >= nvals * 1024) return;
-    const uint32_t vw = (uint32_t)(idx >> 10);
-    const uint32_t j = (idx >> 5) & 31, k = idx & 31;
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nvals * AMAT_WORDS) return;
+    const uint32_t vw = (uint32_t)(idx / AMAT_WORDS), t = (uint32_t)(idx % AMAT_WORDS);
+    const uint32_t set = t >> 8;
+    const uint32_t j = ((t & 255u) >> 4) + (set ? 16 : 0), k = (t & 15u) + (set == 2 ? 16 : 0);
     const uint32_t nvw = 1u << (d.nb - 5);
     const uint32_t w = tile_base(d, vw / nvw) | tile_word(d, (vw % nvw) << 5);
     uint32_t mm = 0;
-    for (uint32_t t = 0; t < 32; t++)
-        if ((d_RTAB[t * 32 + k] >> j) & 1) mm ^= Z[(uint64_t)(w | tile_word(d, t)) * ROWS];
+    for (uint32_t tt = 0; tt < 32; tt++)
+        if ((d_RTAB[tt * 32 + k] >> j) & 1) mm ^= Z[(uint64_t)(w | tile_word(d, tt)) * ROWS];
     Amat[idx] = mm;
 }
 
@@ -2677,10 +2655,10 @@ static int upload_a_and_transform(sot_ctx *c) {
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
-    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * 512, 256)), dim3(256), 0, c->stream, plan.low,
+    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * LOW_BLK_WORDS, 256)), dim3(256), 0, c->stream, plan.low,
                        g.nw / 32, c->TW, c->LM);
     launch_low<0>(c, zb[cur], plan.low);
-    hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * 1024, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
+    hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * AMAT_WORDS, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
                        g.nw / 32, c->Amat);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
@@ -2711,8 +2689,8 @@ int qc_init(sot_ctx *c) {
     g.nw = 1ull << (m - 5);
     SOT_TRY(dev_alloc(c, (void **)&c->Z0, g.nw * ROWS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->Z1, g.nw * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * 1024 * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * 512 * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * AMAT_WORDS * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * LOW_BLK_WORDS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->sbv, (cf.cols * 128 / 32 + 2) * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));

@@ -2,6 +2,8 @@
 // broadcast from LDS (ds_read_b128, same address in every lane).
 //   A: 16 waves per CU, one row half per wave (today's kernel): one broadcast read per 4 XANDs
 //   B:  8 waves per CU, both row halves in one wave: one broadcast read per 8 XANDs, 2 waves per SIMD
+//   C: 16 waves per CU, both row halves in one wave (twice the data per CU: the other half of the tile lives in
+//      registers instead of LDS): one broadcast read per 8 XANDs, 4 waves per SIMD
 // Same number of XANDs in both; prints ms and XAND wave-instructions/s.
 //   hipcc --offload-arch=gfx950 -O3 -o mask_share mask_share.hip
 #include <hip/hip_runtime.h>
@@ -10,8 +12,8 @@
 #define XAND(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x78)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int HALVES>
-__global__ void __launch_bounds__(HALVES == 1 ? 1024 : 512) k(uint32_t *out, const uint32_t *seed, int reps) {
+template <int HALVES, int THREADS>
+__global__ void __launch_bounds__(THREADS) k(uint32_t *out, const uint32_t *seed, int reps) {
     __shared__ uint4 M[16 * 128];  // 16 waves x one 2 KiB mask block
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < 16 * 128; i += blockDim.x) M[i] = make_uint4(seed[i & 255], seed[(i + 1) & 255], seed[(i + 2) & 255], seed[(i + 3) & 255]);
@@ -64,17 +66,18 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 400;
-    for (int var = 0; var < 2; var++)
+    for (int var = 0; var < 3; var++)
         for (int it = 0; it < 3; it++) {
             CK(hipEventRecord(e0));
-            if (var == 0) hipLaunchKernelGGL(k<1>, dim3(256), dim3(1024), 0, 0, out, seed, reps);
-            else hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, seed, reps);
+            if (var == 0) hipLaunchKernelGGL((k<1, 1024>), dim3(256), dim3(1024), 0, 0, out, seed, reps);
+            else if (var == 1) hipLaunchKernelGGL((k<2, 512>), dim3(256), dim3(512), 0, 0, out, seed, reps);
+            else hipLaunchKernelGGL((k<2, 1024>), dim3(256), dim3(1024), 0, 0, out, seed, reps);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const double xands = 256.0 * 16 * 512 * reps;  // wave-instructions: 256 CUs x 16 wave-halves x 512 per level
+            const double xands = 256.0 * (var == 2 ? 32 : 16) * 512 * reps;  // wave-instructions: 256 CUs x wave-halves x 512 per level
             printf("%s: %.3f ms, %.3e XAND wave-instr/s, %.2f cycles per XAND and SIMD at 2.4 GHz\n",
-                   var ? "B both row halves per wave ( 8 waves/CU)" : "A one row half per wave    (16 waves/CU)", ms,
+                   var == 2 ? "C both row halves per wave (16 waves/CU)" : var ? "B both row halves per wave ( 8 waves/CU)" : "A one row half per wave    (16 waves/CU)", ms,
                    xands / (ms * 1e-3), ms * 1e-3 * 2.4e9 / (xands / 1024));
         }
     CK(hipGetLastError());
