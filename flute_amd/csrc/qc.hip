@@ -31,9 +31,6 @@
 // without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
 #define QC_EXP 0
 #endif
-#ifndef QC_MIDMASK_LDS
-#define QC_MIDMASK_LDS 1  // k_mid: level masks through the wave's own LDS slots (1) or through the scalar unit (0)
-#endif
 #ifndef LOW_RING
 #define LOW_RING 5  // k_fft_low: mask blocks (1.5 KiB) in a value word's 8 KiB ring, LOW_RING - 1 of them loaded ahead
 #endif
@@ -1632,7 +1629,7 @@ __global__ void __launch_bounds__(TL_THREADS)
 // ------------------------------------------------------------------------------------------------
 // K4m: the 16-plane passes (levels 9..12 and 13..16). Tile = 16 values x 16 planes x 64 rows, slot = lv * 16 + plane,
 // lv bit b <-> level rmin + b. One wave per butterfly and level (8 waves), all 16 planes in registers, twiddle
-// matrices as precomputed mask words MT[outer][b][butterfly][j][k] (k_build_midmasks) read through the scalar unit.
+// matrices as precomputed mask words MT[outer][b][butterfly][192] (k_build_midmasks) staged in LDS (see k_mid).
 #define MD_THREADS 512
 #define MD_WAVES (MD_THREADS / 64)
 
@@ -1652,30 +1649,8 @@ __device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
     return r;
 }
 
-// acc[k] ^= XOR_j y[j] & M[j][k], j, k < 16; M wave-uniform, 128-byte aligned, two rows per pair of tuples
-__device__ __forceinline__ void apply_masks16(uint32_t acc[16], const uint32_t y[16], const uint32_t *M) {
-    u32x16 a0, a1, b0, b1;
-    SLOAD32(a0, a1, M);
-#pragma unroll
-    for (int j = 0; j < 16; j += 4) {
-        SWAIT32(a0, a1);
-        SLOAD32(b0, b1, M + (j + 2) * 16);
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j], a0[k]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 1], a1[k]);
-        SWAIT32(b0, b1);
-        if (j + 4 < 16) SLOAD32(a0, a1, M + (j + 4) * 16);
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 2], b0[k]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], y[j + 3], b1[k]);
-    }
-}
-
 // Persistent, two workgroups per CU (tiles idx = blockIdx.x, + gridDim.x, ...): the next tile's 32 granules per
-// thread are fetched while the four levels of the current one run, and the 1 KiB of masks of a level is pulled into
-// L2 one level ahead (mask_prefetch).
+// thread are fetched while the four levels of the current one run.
 template <bool INV, bool PRUNE_LAST>
 __global__ void __launch_bounds__(MD_THREADS)
     k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT, uint32_t ntiles) {
@@ -1703,14 +1678,6 @@ __global__ void __launch_bounds__(MD_THREADS)
     };
     uint32_t idx = tile_of(0);
     const uint32_t bf = wave;
-    // the 4 x 1 KiB of masks of a tile (level lane / 16, line lane % 16), touched one tile ahead; pf stays live up to
-    // the drain at the end of the kernel (see mask_prefetch)
-    auto masks_ahead = [&](uint32_t &pf, uint32_t i2) {
-        const uint32_t o2 = pext32(tile_base(d, tile_no(d, i2)), mask_hi);
-        mask_prefetch(pf, MT + ((((uint64_t)o2 * 4 + (lane >> 4)) * 8 + bf) << 8) + (lane & 15) * 16);
-    };
-    uint32_t pf = 0;
-    if (!QC_MIDMASK_LDS) masks_ahead(pf, idx);
     regs_t v = fetch(idx);
 #pragma unroll 1
     for (uint32_t sq = 0; sq < nseq; sq++) {
@@ -1724,20 +1691,17 @@ __global__ void __launch_bounds__(MD_THREADS)
         {
             const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
             v = fetch(nidx);
-            if (!QC_MIDMASK_LDS && !tile_rh(d, nidx)) masks_ahead(pf, nidx);
         }
-        // QC_MIDMASK_LDS: the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and
-        // parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
+        // the 768 B of masks of each of the four levels (48 x 16 B, in a 1 KiB slot), one 16-byte piece per lane, fetched
+        // now and parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
         // registers) and read back as VGPR operands: no scalar-memory stream whose latency the level would expose
         // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
         // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
         u32x16 mk;
-        if (QC_MIDMASK_LDS) {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
-                mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
-            }
+        for (int b = 0; b < 4; b++) {
+            const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
+            mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
         }
 #pragma unroll
         for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
@@ -1746,7 +1710,6 @@ __global__ void __launch_bounds__(MD_THREADS)
             const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
             uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
             uint32_t *py = px + (16u << b) * TL_ROWS;
-            const uint32_t *M = MT + ((QC_EXP & 32) ? 0 : ((((uint64_t)outer * 4 + b) * 8 + bf) << 8));
             uint32_t x[16], y[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -1757,22 +1720,49 @@ __global__ void __launch_bounds__(MD_THREADS)
 #pragma unroll
                 for (int k = 0; k < 16; k++) y[k] ^= x[k];
             }
-            if (QC_MIDMASK_LDS) {
+            {
+                // tau (x) y Karatsuba-style over GF(2^8)[t]: the 16 x 16 matrix is [[A, X], [B, A + B]] in 8 x 8 blocks, so
+                // x_lo ^= A y_lo ^ X y_hi, x_hi ^= (A + B)(y_lo ^ y_hi) ^ A y_lo: 192 masks instead of 256
                 uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
                 R[lane] = make_uint4(mk[4 * b + 0], mk[4 * b + 1], mk[4 * b + 2], mk[4 * b + 3]);
+                uint32_t t1[8], sm[8];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
+                for (int k = 0; k < 8; k++) t1[k] = 0, sm[k] = y[k] ^ y[k + 8];
 #pragma unroll
-                    for (int kq = 0; kq < 4; kq++) {
-                        const uint4 m = R[j * 4 + kq];
-                        x[4 * kq + 0] = XAND(x[4 * kq + 0], y[j], m.x);
-                        x[4 * kq + 1] = XAND(x[4 * kq + 1], y[j], m.y);
-                        x[4 * kq + 2] = XAND(x[4 * kq + 2], y[j], m.z);
-                        x[4 * kq + 3] = XAND(x[4 * kq + 3], y[j], m.w);
+                for (int j = 0; j < 8; j++) {
+#pragma unroll
+                    for (int kq = 0; kq < 2; kq++) {
+                        const uint4 m = R[j * 2 + kq];  // A
+                        t1[4 * kq + 0] = XAND(t1[4 * kq + 0], y[j], m.x);
+                        t1[4 * kq + 1] = XAND(t1[4 * kq + 1], y[j], m.y);
+                        t1[4 * kq + 2] = XAND(t1[4 * kq + 2], y[j], m.z);
+                        t1[4 * kq + 3] = XAND(t1[4 * kq + 3], y[j], m.w);
                     }
                 }
-            } else {
-                apply_masks16(x, y, M);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+#pragma unroll
+                    for (int kq = 0; kq < 2; kq++) {
+                        const uint4 m = R[16 + j * 2 + kq];  // X
+                        x[4 * kq + 0] = XAND(x[4 * kq + 0], y[8 + j], m.x);
+                        x[4 * kq + 1] = XAND(x[4 * kq + 1], y[8 + j], m.y);
+                        x[4 * kq + 2] = XAND(x[4 * kq + 2], y[8 + j], m.z);
+                        x[4 * kq + 3] = XAND(x[4 * kq + 3], y[8 + j], m.w);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+#pragma unroll
+                    for (int kq = 0; kq < 2; kq++) {
+                        const uint4 m = R[32 + j * 2 + kq];  // A + B
+                        x[8 + 4 * kq + 0] = XAND(x[8 + 4 * kq + 0], sm[j], m.x);
+                        x[8 + 4 * kq + 1] = XAND(x[8 + 4 * kq + 1], sm[j], m.y);
+                        x[8 + 4 * kq + 2] = XAND(x[8 + 4 * kq + 2], sm[j], m.z);
+                        x[8 + 4 * kq + 3] = XAND(x[8 + 4 * kq + 3], sm[j], m.w);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] ^= t1[k], x[k + 8] ^= t1[k];
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
@@ -1790,22 +1780,27 @@ __global__ void __launch_bounds__(MD_THREADS)
         }
         __syncthreads();
     }
-    mask_prefetch_drain(pf);
 }
 
-// MT[((outer * 4 + b) * 8 + bf)][j][k] = all-ones iff output plane k of (twiddle (x) y) takes input plane j
+// MT[((outer * 4 + b) * 8 + bf) * 256 + t], t < 192 (the rest of the 1 KiB slot stays zero): all-ones iff output plane kk of
+// (twiddle (x) y) takes input plane jj, with set = t / 64, j = t / 8 % 8, k = t % 8 and
+// (kk, jj) = (k, j) [A], (k, 8 + j) [X], (8 + k, 8 + j) [A + B]
 __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, uint32_t nouter,
                                  const uint32_t *__restrict__ TW, uint32_t *__restrict__ MT) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (outer, b, bf, j)
-    if (idx >= nouter * 4 * 8 * 16) return;
-    const uint32_t j = idx & 15, bf = (idx >> 4) & 7, b = (idx >> 7) & 3, outer = idx >> 9;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (outer, b, bf, piece of 4 words)
+    if (idx >= nouter * 4 * 8 * 64) return;
+    const uint32_t pc = idx & 63, bf = (idx >> 6) & 7, b = (idx >> 9) & 3, outer = idx >> 11;
     const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
     const uint32_t w = pdep32(outer, mask_hi) | tile_word(d, lvx << 4);
     const uint32_t r = rmin + b;
     const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
     uint32_t rows[16];
     tw_rows<16>(TW, q, 0, rows);
-    for (uint32_t k = 0; k < 16; k++) MT[(uint64_t)idx * 16 + k] = 0u - ((rows[k] >> j) & 1u);
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t t = pc * 4 + c, set = t >> 6, j = (t >> 3) & 7, k = t & 7;
+        const uint32_t kk = set == 2 ? 8 + k : k, jj = set ? 8 + j : j;
+        MT[(uint64_t)idx * 4 + c] = t < 192 ? 0u - ((rows[kk] >> jj) & 1u) : 0u;
+    }
 }
 
 // the 32-plane word levels of the low tile (slot = lv * 32 + plane, lv bit b <-> level m - 4 - nl + b): one wave per
@@ -1825,12 +1820,37 @@ __device__ __forceinline__ void low_word_item(const uint32_t *lds, uint32_t xs, 
     }
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) xn[kk] = lds[(xs + C0 + kk) * TL_ROWS + lane];
+    // rows[kk] = the 16 x 32 strip [M_lo | M_hi] of the twiddle matrix for these 16 output planes; both 16 x 16 halves are
+    // matrices of GF(2^16) elements, [[a, x], [b, a + b]] in 8 x 8 blocks, so per half (u = 16 input planes of y)
+    //   out_lo ^= a u_lo ^ x u_hi,  out_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo:   192 scalar-mask XANDs instead of 256
+    uint32_t t1[8];
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
+    for (int kk = 0; kk < 8; kk++) t1[kk] = 0;
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) xn[kk] = XAND(xn[kk], y[j], 0u - ((rows[kk] >> j) & 1u));
-        __builtin_amdgcn_sched_barrier(0);
+    for (int h = 0; h < 2; h++) {
+        const int j0 = 16 * h;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) t1[kk] = XAND(t1[kk], y[j0 + j], 0u - ((rows[kk] >> (j0 + j)) & 1u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) xn[kk] = XAND(xn[kk], y[j0 + 8 + j], 0u - ((rows[kk] >> (j0 + 8 + j)) & 1u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t sm = y[j0 + j] ^ y[j0 + 8 + j];
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) xn[8 + kk] = XAND(xn[8 + kk], sm, 0u - ((rows[8 + kk] >> (j0 + 8 + j)) & 1u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) xn[kk] ^= t1[kk], xn[8 + kk] ^= t1[kk];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) yn[kk] = INV ? y[C0 + kk] : y[C0 + kk] ^ xn[kk];
 }
@@ -2702,9 +2722,9 @@ int qc_init(sot_ctx *c) {
     c->qc_plan = plan;
     SOT_TRY(dev_alloc(c, (void **)&c->MT1, 16ull * 4 * 8 * 256 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->MT2, 256ull * 4 * 8 * 256 * 4));
-    hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
+    hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 64 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
                        16u, c->TW, c->MT1);
-    hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
+    hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 64 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
                        13u, 256u, c->TW, c->MT2);
     SOT_HIP(hipGetLastError());
     {
