@@ -1803,6 +1803,33 @@ __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, u
     }
 }
 
+// acc ^= M u for the N x N block M = rows[K0 + k] bits J0 + j (k, j < N) of a twiddle matrix, where M is the matrix of an
+// element of GF(2^N): over the tower GF(2^N) = GF(2^(N/2))[t], t^2 = t + zeta, M = [[a, x], [b, a + b]] in blocks, so
+//   acc_lo ^= a u_lo ^ x u_hi,   acc_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo
+// three half-size products instead of four, recursively down to 4 x 4 (scalar masks: a v_bitop3 with an SGPR operand
+// costs 5 cycles, a plain v_xor 3, so trading 7 XANDs of 16 for 3-4 XORs pays twice over).
+template <int N, int K0, int J0>
+__device__ __forceinline__ void kara_acc(uint32_t *acc, const uint32_t *u, const uint32_t *rows) {
+    if constexpr (N <= 4) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+#pragma unroll
+            for (int k = 0; k < N; k++) acc[k] = XAND(acc[k], u[j], 0u - ((rows[K0 + k] >> (J0 + j)) & 1u));
+        }
+    } else {
+        constexpr int H = N / 2;
+        uint32_t t1[H], sm[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = u[k] ^ u[k + H];
+        kara_acc<H, K0, J0>(t1, u, rows);
+        kara_acc<H, K0, J0 + H>(acc, u + H, rows);
+        kara_acc<H, K0 + H, J0 + H>(acc + H, sm, rows);
+#pragma unroll
+        for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // the 32-plane word levels of the low tile (slot = lv * 32 + plane, lv bit b <-> level m - 4 - nl + b): one wave per
 // (butterfly, half of the output planes); results stay in registers across the barrier that separates the reads
 // of a level from its writes.
@@ -1821,36 +1848,9 @@ __device__ __forceinline__ void low_word_item(const uint32_t *lds, uint32_t xs, 
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) xn[kk] = lds[(xs + C0 + kk) * TL_ROWS + lane];
     // rows[kk] = the 16 x 32 strip [M_lo | M_hi] of the twiddle matrix for these 16 output planes; both 16 x 16 halves are
-    // matrices of GF(2^16) elements, [[a, x], [b, a + b]] in 8 x 8 blocks, so per half (u = 16 input planes of y)
-    //   out_lo ^= a u_lo ^ x u_hi,  out_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo:   192 scalar-mask XANDs instead of 256
-    uint32_t t1[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) t1[kk] = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int j0 = 16 * h;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) t1[kk] = XAND(t1[kk], y[j0 + j], 0u - ((rows[kk] >> (j0 + j)) & 1u));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) xn[kk] = XAND(xn[kk], y[j0 + 8 + j], 0u - ((rows[kk] >> (j0 + 8 + j)) & 1u));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t sm = y[j0 + j] ^ y[j0 + 8 + j];
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) xn[8 + kk] = XAND(xn[8 + kk], sm, 0u - ((rows[8 + kk] >> (j0 + 8 + j)) & 1u));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 8; kk++) xn[kk] ^= t1[kk], xn[8 + kk] ^= t1[kk];
+    // matrices of GF(2^16) elements: kara_acc
+    kara_acc<16, 0, 0>(xn, y, rows);
+    kara_acc<16, 0, 16>(xn, y + 16, rows);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) yn[kk] = INV ? y[C0 + kk] : y[C0 + kk] ^ xn[kk];
 }
