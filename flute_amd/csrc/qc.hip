@@ -1806,11 +1806,14 @@ __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, u
 // acc ^= M u for the N x N block M = rows[K0 + k] bits J0 + j (k, j < N) of a twiddle matrix, where M is the matrix of an
 // element of GF(2^N): over the tower GF(2^N) = GF(2^(N/2))[t], t^2 = t + zeta, M = [[a, x], [b, a + b]] in blocks, so
 //   acc_lo ^= a u_lo ^ x u_hi,   acc_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo
-// three half-size products instead of four, recursively down to 4 x 4 (scalar masks: a v_bitop3 with an SGPR operand
+// three half-size products instead of four, recursively down to 2 x 2 (measured: 3.44 -> 3.28 -> 3.22 ms per step for bases 8, 4, 2; scalar masks: a v_bitop3 with an SGPR operand
 // costs 5 cycles, a plain v_xor 3, so trading 7 XANDs of 16 for 3-4 XORs pays twice over).
+#ifndef KARA_BASE
+#define KARA_BASE 2
+#endif
 template <int N, int K0, int J0>
 __device__ __forceinline__ void kara_acc(uint32_t *acc, const uint32_t *u, const uint32_t *rows) {
-    if constexpr (N <= 4) {
+    if constexpr (N <= KARA_BASE) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
 #pragma unroll
