@@ -1443,6 +1443,46 @@ __device__ __forceinline__ void apply_masks16_lds(uint32_t acc[16], const uint32
         }
     }
 }
+// acc ^= M16 v for a 16 x 16 set M[4 j + kq] whose matrix (both packed halves, if packed) is that of GF(2^16) elements:
+// one more Karatsuba level on the same table, [[a, x], [b, a + b]] in 8 x 8 blocks; the b block (j < 8, k >= 8) is never
+// read: 48 broadcast reads instead of 64
+__device__ __forceinline__ void apply_kara16_lds(uint32_t acc[16], const uint32_t *v, const uint4 *M) {
+    uint32_t t1[8], sm[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t1[k] = 0, sm[k] = v[k] ^ v[k + 8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int kq = 0; kq < 2; kq++) {
+            const uint4 m = M[j * 4 + kq];  // a
+            t1[4 * kq + 0] = XAND(t1[4 * kq + 0], v[j], m.x);
+            t1[4 * kq + 1] = XAND(t1[4 * kq + 1], v[j], m.y);
+            t1[4 * kq + 2] = XAND(t1[4 * kq + 2], v[j], m.z);
+            t1[4 * kq + 3] = XAND(t1[4 * kq + 3], v[j], m.w);
+        }
+    }
+#pragma unroll
+    for (int j = 8; j < 16; j++) {
+#pragma unroll
+        for (int kq = 0; kq < 2; kq++) {
+            const uint4 m = M[j * 4 + kq];  // x
+            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
+            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
+            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
+            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], v[j], m.w);
+        }
+#pragma unroll
+        for (int kq = 2; kq < 4; kq++) {
+            const uint4 m = M[j * 4 + kq];  // a + b
+            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], sm[j - 8], m.x);
+            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], sm[j - 8], m.y);
+            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], sm[j - 8], m.z);
+            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], sm[j - 8], m.w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] ^= t1[k], acc[k + 8] ^= t1[k];
+}
 template <int I, bool INV>
 __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
     const uint32_t A = lowmask(I);
@@ -1457,7 +1497,7 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
     uint32_t a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a1[k] = 0;
-    apply_masks16_lds<16>(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
+    apply_kara16_lds(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
     uint32_t S[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) S[j] = BFI(P[j] ^ (P[j] >> SH), P[j + 8] ^ (P[j + 8] << SH), A);
@@ -1480,7 +1520,7 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
 __device__ __forceinline__ void amat_block0(const uint32_t W[32], const uint4 *M, uint32_t t1[16], uint32_t t2[16]) {
 #pragma unroll
     for (int k = 0; k < 16; k++) t1[k] = 0, t2[k] = 0;
-    apply_masks16_lds<16>(t1, W, M);
+    apply_kara16_lds(t1, W, M);
     apply_masks16_lds<8>(t2, W + 16, M + 64);
 }
 __device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, const uint32_t t1[16], uint32_t t2[16]) {
@@ -1488,7 +1528,7 @@ __device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, cons
     uint32_t sm[16], t3[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[j] = W[j] ^ W[j + 16], t3[j] = 0;
-    apply_masks16_lds<16>(t3, sm, M + 32);
+    apply_kara16_lds(t3, sm, M + 32);
 #pragma unroll
     for (int k = 0; k < 16; k++) W[k] = t1[k] ^ t2[k], W[k + 16] = t3[k] ^ t1[k];
 }
