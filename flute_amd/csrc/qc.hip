@@ -1443,45 +1443,38 @@ __device__ __forceinline__ void apply_masks16_lds(uint32_t acc[16], const uint32
         }
     }
 }
-// acc ^= M16 v for a 16 x 16 set M[4 j + kq] whose matrix (both packed halves, if packed) is that of GF(2^16) elements:
-// one more Karatsuba level on the same table, [[a, x], [b, a + b]] in 8 x 8 blocks; the b block (j < 8, k >= 8) is never
-// read: 48 broadcast reads instead of 64
-__device__ __forceinline__ void apply_kara16_lds(uint32_t acc[16], const uint32_t *v, const uint4 *M) {
-    uint32_t t1[8], sm[8];
+// acc ^= B v for the N x N block B = rows K0.., columns J0.. of a mask set M[4 j + k / 4] (16 output planes per j) whose
+// matrix (both packed halves, if packed) is that of GF(2^N) elements: Karatsuba down to 4 x 4 on the SAME table,
+// [[a, x], [b, a + b]] in blocks; the b blocks are never read: 36 broadcast reads per 16 x 16 block instead of 64
+// (12 instead of 16 per 8 x 8). acc and v are relative to the block.
+#ifndef KARA_LDS_BASE
+#define KARA_LDS_BASE 4
+#endif
+template <int N, int K0, int J0>
+__device__ __forceinline__ void kara_lds(uint32_t *acc, const uint32_t *v, const uint4 *M) {
+    if constexpr (N <= KARA_LDS_BASE) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) t1[k] = 0, sm[k] = v[k] ^ v[k + 8];
+        for (int j = 0; j < N; j++) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-#pragma unroll
-        for (int kq = 0; kq < 2; kq++) {
-            const uint4 m = M[j * 4 + kq];  // a
-            t1[4 * kq + 0] = XAND(t1[4 * kq + 0], v[j], m.x);
-            t1[4 * kq + 1] = XAND(t1[4 * kq + 1], v[j], m.y);
-            t1[4 * kq + 2] = XAND(t1[4 * kq + 2], v[j], m.z);
-            t1[4 * kq + 3] = XAND(t1[4 * kq + 3], v[j], m.w);
+            for (int kq = 0; kq < N / 4; kq++) {
+                const uint4 m = M[(J0 + j) * 4 + K0 / 4 + kq];
+                acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
+                acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
+                acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
+                acc[4 * kq + 3] = XAND(acc[4 * kq + 3], v[j], m.w);
+            }
         }
+    } else {
+        constexpr int H = N / 2;
+        uint32_t t1[H], sm[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = v[k] ^ v[k + H];
+        kara_lds<H, K0, J0>(t1, v, M);
+        kara_lds<H, K0, J0 + H>(acc, v + H, M);
+        kara_lds<H, K0 + H, J0 + H>(acc + H, sm, M);
+#pragma unroll
+        for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
     }
-#pragma unroll
-    for (int j = 8; j < 16; j++) {
-#pragma unroll
-        for (int kq = 0; kq < 2; kq++) {
-            const uint4 m = M[j * 4 + kq];  // x
-            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
-            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
-            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
-            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], v[j], m.w);
-        }
-#pragma unroll
-        for (int kq = 2; kq < 4; kq++) {
-            const uint4 m = M[j * 4 + kq];  // a + b
-            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], sm[j - 8], m.x);
-            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], sm[j - 8], m.y);
-            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], sm[j - 8], m.z);
-            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], sm[j - 8], m.w);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] ^= t1[k], acc[k + 8] ^= t1[k];
 }
 template <int I, bool INV>
 __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
@@ -1497,14 +1490,16 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
     uint32_t a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a1[k] = 0;
-    apply_kara16_lds(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
+    kara_lds<16, 0, 0>(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
     uint32_t S[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) S[j] = BFI(P[j] ^ (P[j] >> SH), P[j + 8] ^ (P[j + 8] << SH), A);
     uint32_t a3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a3[k] = 0;
-    apply_masks16_lds<8>(a3, S, M + 64);  // x + y positions: (A + B) s
+    // x + y positions: (A + B) s; per 8 output planes the two packed 8 x 8 halves are matrices of GF(2^8) elements
+    kara_lds<8, 0, 0>(a3, S, M + 64);
+    kara_lds<8, 8, 0>(a3 + 8, S, M + 64);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         W[k] = XAND(W[k], a1[k] ^ (a1[k] >> SH), A);
@@ -1517,18 +1512,24 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
 }
 // pointwise multiply by FFT(a), same decomposition, the 768 mask words of a value word as two blocks of 384:
 // block 0 = A | X[0..7], block 1 = X[8..15] | (A + B)
-__device__ __forceinline__ void amat_block0(const uint32_t W[32], const uint4 *M, uint32_t t1[16], uint32_t t2[16]) {
+__device__ __forceinline__ void amat_block0(const uint32_t W[32], const uint4 *M, uint32_t t1[16], uint32_t tt[8]) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) t1[k] = 0, t2[k] = 0;
-    apply_kara16_lds(t1, W, M);
-    apply_masks16_lds<8>(t2, W + 16, M + 64);
+    for (int k = 0; k < 16; k++) t1[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tt[k] = 0;
+    kara_lds<16, 0, 0>(t1, W, M);          // A w_lo
+    kara_lds<8, 0, 0>(tt, W + 16, M + 64);  // the a block of X times the low half of w_hi
 }
-__device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, const uint32_t t1[16], uint32_t t2[16]) {
-    apply_masks16_lds<8>(t2, W + 24, M);
+__device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, const uint32_t t1[16], const uint32_t tt[8]) {
+    uint32_t t2[16], sx[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t2[k] = tt[k], t2[k + 8] = tt[k], sx[k] = W[16 + k] ^ W[24 + k];
+    kara_lds<8, 0, 0>(t2, W + 24, M);   // x block of X
+    kara_lds<8, 8, 0>(t2 + 8, sx, M);   // (a + b) block of X
     uint32_t sm[16], t3[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[j] = W[j] ^ W[j + 16], t3[j] = 0;
-    apply_kara16_lds(t3, sm, M + 32);
+    kara_lds<16, 0, 0>(t3, sm, M + 32);  // (A + B)(w_lo + w_hi)
 #pragma unroll
     for (int k = 0; k < 16; k++) W[k] = t1[k] ^ t2[k], W[k + 16] = t3[k] ^ t1[k];
 }
@@ -1986,7 +1987,7 @@ __global__ void __launch_bounds__(64 * NVW)
         for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
 #pragma unroll
         for (int b = 0; b < AH; b++) R[b * 96 + lane] = s0[b], R[b * 96 + l2] = s1[b];
-        uint32_t t1[16], t2[16];
+        uint32_t t1[16], t2[8];
 #pragma unroll
         for (int b = 0; b < NBLK; b++) {
             uint4 n0, n1;
