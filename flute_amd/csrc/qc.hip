@@ -1450,9 +1450,9 @@ __device__ __forceinline__ void apply_masks16_lds(uint32_t acc[16], const uint32
 #ifndef KARA_LDS_BASE
 #define KARA_LDS_BASE 4
 #endif
-template <int N, int K0, int J0>
+template <int N, int K0, int J0, int BASE = KARA_LDS_BASE>
 __device__ __forceinline__ void kara_lds(uint32_t *acc, const uint32_t *v, const uint4 *M) {
-    if constexpr (N <= KARA_LDS_BASE) {
+    if constexpr (N <= BASE) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
 #pragma unroll
@@ -1469,9 +1469,9 @@ __device__ __forceinline__ void kara_lds(uint32_t *acc, const uint32_t *v, const
         uint32_t t1[H], sm[H];
 #pragma unroll
         for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = v[k] ^ v[k + H];
-        kara_lds<H, K0, J0>(t1, v, M);
-        kara_lds<H, K0, J0 + H>(acc, v + H, M);
-        kara_lds<H, K0 + H, J0 + H>(acc + H, sm, M);
+        kara_lds<H, K0, J0, BASE>(t1, v, M);
+        kara_lds<H, K0, J0 + H, BASE>(acc, v + H, M);
+        kara_lds<H, K0 + H, J0 + H, BASE>(acc + H, sm, M);
 #pragma unroll
         for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
     }
@@ -1670,7 +1670,7 @@ __global__ void __launch_bounds__(TL_THREADS)
 // ------------------------------------------------------------------------------------------------
 // K4m: the 16-plane passes (levels 9..12 and 13..16). Tile = 16 values x 16 planes x 64 rows, slot = lv * 16 + plane,
 // lv bit b <-> level rmin + b. One wave per butterfly and level (8 waves), all 16 planes in registers, twiddle
-// matrices as precomputed mask words MT[outer][b][butterfly][192] (k_build_midmasks) staged in LDS (see k_mid).
+// matrices as precomputed mask words MT[outer][b][butterfly][j][k] (k_build_midmasks) staged in LDS (see k_mid).
 #define MD_THREADS 512
 #define MD_WAVES (MD_THREADS / 64)
 
@@ -1733,8 +1733,7 @@ __global__ void __launch_bounds__(MD_THREADS)
             const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
             v = fetch(nidx);
         }
-        // the 768 B of masks of each of the four levels (48 x 16 B, in a 1 KiB slot), one 16-byte piece per lane, fetched
-        // now and parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
+        // the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
         // registers) and read back as VGPR operands: no scalar-memory stream whose latency the level would expose
         // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
         // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
@@ -1762,48 +1761,12 @@ __global__ void __launch_bounds__(MD_THREADS)
                 for (int k = 0; k < 16; k++) y[k] ^= x[k];
             }
             {
-                // tau (x) y Karatsuba-style over GF(2^8)[t]: the 16 x 16 matrix is [[A, X], [B, A + B]] in 8 x 8 blocks, so
-                // x_lo ^= A y_lo ^ X y_hi, x_hi ^= (A + B)(y_lo ^ y_hi) ^ A y_lo: 192 masks instead of 256
+                // x ^= tau (x) y, Karatsuba-style (kara_lds) with 8 x 8 blocks (48 broadcast reads instead of 64) in the forward
+                // kernel and 4 x 4 blocks (36) in the inverse one: forward with 4 x 4 blocks needs 129 VGPRs, one too many
+                // for two workgroups per CU (1.50 ms per step instead of 1.17; forcing 128 by attribute: 1.22)
                 uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
                 R[lane] = make_uint4(mk[4 * b + 0], mk[4 * b + 1], mk[4 * b + 2], mk[4 * b + 3]);
-                uint32_t t1[8], sm[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) t1[k] = 0, sm[k] = y[k] ^ y[k + 8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-#pragma unroll
-                    for (int kq = 0; kq < 2; kq++) {
-                        const uint4 m = R[j * 2 + kq];  // A
-                        t1[4 * kq + 0] = XAND(t1[4 * kq + 0], y[j], m.x);
-                        t1[4 * kq + 1] = XAND(t1[4 * kq + 1], y[j], m.y);
-                        t1[4 * kq + 2] = XAND(t1[4 * kq + 2], y[j], m.z);
-                        t1[4 * kq + 3] = XAND(t1[4 * kq + 3], y[j], m.w);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-#pragma unroll
-                    for (int kq = 0; kq < 2; kq++) {
-                        const uint4 m = R[16 + j * 2 + kq];  // X
-                        x[4 * kq + 0] = XAND(x[4 * kq + 0], y[8 + j], m.x);
-                        x[4 * kq + 1] = XAND(x[4 * kq + 1], y[8 + j], m.y);
-                        x[4 * kq + 2] = XAND(x[4 * kq + 2], y[8 + j], m.z);
-                        x[4 * kq + 3] = XAND(x[4 * kq + 3], y[8 + j], m.w);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-#pragma unroll
-                    for (int kq = 0; kq < 2; kq++) {
-                        const uint4 m = R[32 + j * 2 + kq];  // A + B
-                        x[8 + 4 * kq + 0] = XAND(x[8 + 4 * kq + 0], sm[j], m.x);
-                        x[8 + 4 * kq + 1] = XAND(x[8 + 4 * kq + 1], sm[j], m.y);
-                        x[8 + 4 * kq + 2] = XAND(x[8 + 4 * kq + 2], sm[j], m.z);
-                        x[8 + 4 * kq + 3] = XAND(x[8 + 4 * kq + 3], sm[j], m.w);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] ^= t1[k], x[k + 8] ^= t1[k];
+                kara_lds<16, 0, 0, INV ? 4 : 8>(x, y, R);
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
@@ -1823,25 +1786,19 @@ __global__ void __launch_bounds__(MD_THREADS)
     }
 }
 
-// MT[((outer * 4 + b) * 8 + bf) * 256 + t], t < 192 (the rest of the 1 KiB slot stays zero): all-ones iff output plane kk of
-// (twiddle (x) y) takes input plane jj, with set = t / 64, j = t / 8 % 8, k = t % 8 and
-// (kk, jj) = (k, j) [A], (k, 8 + j) [X], (8 + k, 8 + j) [A + B]
+// MT[((outer * 4 + b) * 8 + bf)][j][k] = all-ones iff output plane k of (twiddle (x) y) takes input plane j
 __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, uint32_t nouter,
                                  const uint32_t *__restrict__ TW, uint32_t *__restrict__ MT) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (outer, b, bf, piece of 4 words)
-    if (idx >= nouter * 4 * 8 * 64) return;
-    const uint32_t pc = idx & 63, bf = (idx >> 6) & 7, b = (idx >> 9) & 3, outer = idx >> 11;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // (outer, b, bf, j)
+    if (idx >= nouter * 4 * 8 * 16) return;
+    const uint32_t j = idx & 15, bf = (idx >> 4) & 7, b = (idx >> 7) & 3, outer = idx >> 9;
     const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
     const uint32_t w = pdep32(outer, mask_hi) | tile_word(d, lvx << 4);
     const uint32_t r = rmin + b;
     const uint32_t q = ((1u << (d.m - 5)) | (w & ~d.pmw)) >> (d.m - r - 5);
     uint32_t rows[16];
     tw_rows<16>(TW, q, 0, rows);
-    for (uint32_t c = 0; c < 4; c++) {
-        const uint32_t t = pc * 4 + c, set = t >> 6, j = (t >> 3) & 7, k = t & 7;
-        const uint32_t kk = set == 2 ? 8 + k : k, jj = set ? 8 + j : j;
-        MT[(uint64_t)idx * 4 + c] = t < 192 ? 0u - ((rows[kk] >> jj) & 1u) : 0u;
-    }
+    for (uint32_t k = 0; k < 16; k++) MT[(uint64_t)idx * 16 + k] = 0u - ((rows[k] >> j) & 1u);
 }
 
 // acc ^= M u for the N x N block M = rows[K0 + k] bits J0 + j (k, j < N) of a twiddle matrix, where M is the matrix of an
@@ -2766,9 +2723,9 @@ int qc_init(sot_ctx *c) {
     c->qc_plan = plan;
     SOT_TRY(dev_alloc(c, (void **)&c->MT1, 16ull * 4 * 8 * 256 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->MT2, 256ull * 4 * 8 * 256 * 4));
-    hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 64 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
+    hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
                        16u, c->TW, c->MT1);
-    hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 64 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
+    hipLaunchKernelGGL(k_build_midmasks, dim3(256 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid2, plan->mid2_hi,
                        13u, 256u, c->TW, c->MT2);
     SOT_HIP(hipGetLastError());
     {
