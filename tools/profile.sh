@@ -11,5 +11,4 @@ timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- p
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python3 $ARGS --no-prof > $OUT/fetch.log 2>&1 || exit 2
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python3 $ARGS --no-prof > $OUT/write.log 2>&1 || exit 3
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAVES -d $OUT/sq -o sq -- python3 $ARGS --no-prof > $OUT/sq.log 2>&1 || exit 4
-timeout -s KILL 240 rocprofv3 --pmc TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum -d $OUT/req -o req -- python3 $ARGS --no-prof > $OUT/req.log 2>&1 || exit 5
 ls -R $OUT | head -50
