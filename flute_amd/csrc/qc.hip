@@ -28,7 +28,7 @@
 #ifndef QC_EXP
 // profiling experiments only (tools/exp.sh; results are wrong when set): 1 = k_fft_low without word levels,
 // 2 = without intra-word levels, 4 = k_qc_finish without the tail sums, 8 = without the transposes, 16 = k_mid
-// without levels, 32 = k_mid with one cached mask block, 64 = k_mid without the level barriers
+// without levels, 64 = k_mid without the level barriers, 128 = k_top without the unit phases, 256 = without the levels
 #define QC_EXP 0
 #endif
 #ifndef LOW_RING
@@ -962,7 +962,8 @@ __global__ void k_build_tw(uint32_t *__restrict__ TW, uint32_t *__restrict__ TWC
 }
 
 // rows k0 .. k0+N-1 of the matrix of point(q); q and k0 are wave-uniform: everything stays in SGPRs
-template <int N>
+// NT = number of byte tables that q can touch (q < 2^(8 NT))
+template <int N, int NT = 4>
 __device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_t q, uint32_t k0, uint32_t rows[N]) {
     constexpr int AL = N >= 8 ? 32 : 4 * N;  // k0 is a multiple of N: lets the loads merge into s_load_dwordx8
     const uint32_t *tb = (const uint32_t *)__builtin_assume_aligned(TW, 128);
@@ -971,7 +972,12 @@ __device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_
     const uint32_t *t2 = (const uint32_t *)__builtin_assume_aligned(tb + ((512 + ((q >> 16) & 255)) << 5) + k0, AL);
     const uint32_t *t3 = (const uint32_t *)__builtin_assume_aligned(tb + ((768 + (q >> 24)) << 5) + k0, AL);
 #pragma unroll
-    for (int k = 0; k < N; k++) rows[k] = t0[k] ^ t1[k] ^ t2[k] ^ t3[k];
+    for (int k = 0; k < N; k++) {
+        rows[k] = t0[k];
+        if (NT > 1) rows[k] ^= t1[k];
+        if (NT > 2) rows[k] ^= t2[k];
+        if (NT > 3) rows[k] ^= t3[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1058,12 +1064,22 @@ __device__ __forceinline__ typename tile_regs<(1 << NB) / TL_WAVES>::type tile_f
     uint32_t basis[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) basis[j] = 1u << ((uint32_t)(pq >> (5 * (4 + j))) & 31u);
+    // which of the PER granules are not read (beyond the tile, or in the half that is known to be zero): ONE opaque mask,
+    // tested bit by bit. As PER separate loop-invariant conditions they were hoisted out of the persistent loop into SGPR
+    // pairs (k_top<.,9>: 320 SGPR spills), pushed on into VGPRs and from there to scratch -- and every scratch reload
+    // waits for vmcnt(0), i.e. for the prefetched tile: k_top ran 1.8 ms per step instead of 1.6.
+    uint32_t skip = PER * TL_WAVES > nslots ? ~0u << (nslots / TL_WAVES) : 0u;
+    if (d.zero_bit < 4)
+        skip |= ((wave >> d.zero_bit) & 1u) ? ~0u : 0u;
+    else if (d.zero_bit < 32)
+        skip |= d.zero_bit == 4 ? 0xAAAAAAAAu : d.zero_bit == 5 ? 0xCCCCCCCCu : d.zero_bit == 6 ? 0xF0F0F0F0u
+                : d.zero_bit == 7 ? 0xFF00FF00u : 0xFFFF0000u;
+    asm volatile("" : "+s"(skip));
     typename tile_regs<PER>::type v;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const uint32_t s = wave + TL_WAVES * i;
         uint32_t x = 0;
-        if (s < nslots && (d.zero_bit >= 32 || !((s >> d.zero_bit) & 1u))) {
+        if (!((skip >> i) & 1u)) {
             uint32_t w = 0;
 #pragma unroll
             for (int j = 0; j < 5; j++)
@@ -1079,11 +1095,12 @@ template <int NB>
 __device__ __forceinline__ void tile_put(uint32_t *lds, typename tile_regs<(1 << NB) / TL_WAVES>::type v,
                                          const tile_desc &d, uint32_t wave, uint32_t lane) {
     constexpr int PER = (1 << NB) / TL_WAVES;
-    const uint32_t nslots = 1u << d.nb;
+    uint32_t lim = (1u << d.nb) / TL_WAVES;  // slot wave + 16 i exists iff i < lim; opaque: see tile_fetch
+    asm volatile("" : "+s"(lim));
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const uint32_t s = wave + TL_WAVES * i;
-        if (s < nslots) lds[s * TL_ROWS + lane] = v[i];
+        if ((uint32_t)i < lim) lds[s * TL_ROWS + lane] = v[i];
     }
 }
 template <int NB, int WAVES = TL_WAVES>
@@ -1091,7 +1108,8 @@ __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__rest
                                            uint32_t base_w, uint32_t rh, uint32_t wave, uint32_t lane) {
     constexpr int PER = (1 << NB) / WAVES;
     constexpr int LWV = WAVES == 16 ? 4 : WAVES == 8 ? 3 : WAVES == 4 ? 2 : WAVES == 2 ? 1 : 0;
-    const uint32_t nslots = 1u << d.nb;
+    uint32_t lim = (1u << d.nb) >> LWV;  // slot wave + WAVES i exists iff i < lim; opaque: see tile_fetch
+    asm volatile("" : "+s"(lim));
     const uint32_t voff = (((base_w | tile_word(d, wave)) * ROWS) + rh * TL_ROWS + lane) * 4u;
     uint64_t pq = d.posq;  // see tile_fetch
     asm volatile("" : "+s"(pq));
@@ -1101,7 +1119,7 @@ __device__ __forceinline__ void tile_store(const uint32_t *lds, uint32_t *__rest
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const uint32_t s = wave + WAVES * i;
-        if (s < nslots) {
+        if ((uint32_t)i < lim) {
             uint32_t w = 0;
 #pragma unroll
             for (int j = 0; j < 9 - LWV; j++)
@@ -1547,7 +1565,7 @@ template <int K, bool INV>
 __device__ __forceinline__ void reg_bfly(uint32_t x[K], uint32_t y[K], const uint32_t *__restrict__ TW, uint32_t q,
                                          bool pruned) {
     uint32_t rows[K];
-    tw_rows<K>(TW, q, 0, rows);
+    tw_rows<K, 2>(TW, q, 0, rows);  // levels 3 .. 8: q < 2^9
     if (INV && !pruned) {
 #pragma unroll
         for (int k = 0; k < K; k++) y[k] ^= x[k];
@@ -1659,9 +1677,9 @@ __global__ void __launch_bounds__(TL_THREADS)
             const uint32_t nidx = idx + gridDim.x < ntiles ? idx + gridDim.x : idx;
             v = tile_fetch<NB>(Z, d, tile_base(d, tile_no(d, nidx)), tile_rh(d, nidx), wave, lane);
         }
-        if (!INV && up.nsteps) tile_unit_phases<false>(lds, up, mvl);
-        top_levels<INV>(lds, d.nb, TW, wave, lane);
-        if (INV && up.nsteps) tile_unit_phases<true>(lds, up, mvl);
+        if (!INV && up.nsteps && !(QC_EXP & 128)) tile_unit_phases<false>(lds, up, mvl);
+        if (!(QC_EXP & 256)) top_levels<INV>(lds, d.nb, TW, wave, lane);
+        if (INV && up.nsteps && !(QC_EXP & 128)) tile_unit_phases<true>(lds, up, mvl);
         tile_store<NB>(lds, Z, d, base_w, rh, wave, lane);
         __syncthreads();
     }
