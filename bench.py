@@ -155,7 +155,7 @@ def lut_online_bench(fa, cs, lam, B, reps):
             "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "batch": B, "ms_per_batch": dt * 1e3,
             "outputs_equal_plaintext_sbox": ok,
             "note": "wall time of the two calls incl. upload of the masked inputs / output-lambda shares and download of the "
-                    "delta shares (1 byte per gate and instance each way) and per-call device allocation"}
+                    "delta shares (1 byte per gate and instance each way); the device buffers are kept in the circuit between calls"}
 
 
 def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, log2b, reps):
