@@ -1747,12 +1747,9 @@ __global__ void __launch_bounds__(MD_THREADS)
 #pragma unroll
         for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
         __syncthreads();
-        {
-            const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
-            v = fetch(nidx);
-        }
-        // the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and parked in registers; during a level they are staged in the wave's own x slots (free while x and y are in
-        // registers) and read back as VGPR operands: no scalar-memory stream whose latency the level would expose
+        // the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and parked in registers;
+        // during a level they are staged in the wave's own x slots (free while x and y are in registers) and read back as
+        // VGPR operands: no scalar-memory stream whose latency the level would expose
         // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
         // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
         u32x16 mk;
@@ -1760,6 +1757,12 @@ __global__ void __launch_bounds__(MD_THREADS)
         for (int b = 0; b < 4; b++) {
             const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
             mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
+        }
+        // the prefetch of the next tile comes AFTER the mask loads: vector loads return in order, so waiting for masks
+        // issued behind it would wait for the whole prefetch (vmcnt(0)) before the first level
+        {
+            const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
+            v = fetch(nidx);
         }
 #pragma unroll
         for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
