@@ -1388,54 +1388,10 @@ __device__ __forceinline__ uint32_t lowmask(int i) {
 #define BFI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xE4)
 
 // One level on the value word W[32]. Only half of the bit positions of a plane hold y operands, so planes j and
-// j + 16 are packed into one word (y_j at the x positions, y_(j+16) at the y positions) and the 32x32 twiddle
-// matrix is applied with 16 x 32 mask words LMi[j][k] precomputed per (value word, level) by k_build_lowmasks:
-// bit p of LMi[j][k] = bit k of tau(p) (x) 2^j at x positions, of tau(p - 2^I) (x) 2^(j+16) at y positions,
-// uniform + per-position twiddle parts already combined. The masks arrive through scalar loads.
-// The compiler neither keeps these wave-uniform table reads on the scalar unit nor bounds their live ranges, so
-// they are issued explicitly: 16 dwords per s_load, waited for with lgkmcnt(0) (SMEM returns out of order) through
-// an asm that owns the destination registers, double-buffered so that the next row loads during the 32 XANDs.
+// j + 16 are packed into one word (y_j at the x positions, y_(j+16) at the y positions) and the twiddle matrix is
+// applied with mask words precomputed per (value word, level) by k_build_lowmasks: bit p of a mask = one entry of the
+// matrix of tau(p) at x positions, of tau(p - 2^I) at y positions, uniform + per-position twiddle parts already combined.
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-#define SLOAD32(lo, hi, ptr)                                                               \
-    do {                                                                                   \
-        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(lo) : "s"(ptr));               \
-        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(hi) : "s"(ptr));              \
-    } while (0)
-#define SWAIT32(lo, hi) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi))
-
-// acc[k] ^= v & row[k], k < 32, row = 32 consecutive mask words held in two SGPR tuples
-__device__ __forceinline__ void xand_row(uint32_t acc[32], uint32_t v, const u32x16 &lo, const u32x16 &hi) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) acc[k] = XAND(acc[k], v, lo[k]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) acc[16 + k] = XAND(acc[16 + k], v, hi[k]);
-}
-
-// acc[k] = XOR_j v[j] & M[j][k] for NJ rows of 32 masks at M (wave-uniform, 128-byte aligned)
-template <int NJ>
-__device__ __forceinline__ void apply_masks(uint32_t acc[32], const uint32_t v[NJ], const uint32_t *M) {
-#pragma unroll
-    for (int k = 0; k < 32; k++) acc[k] = 0;
-    u32x16 a0, a1, b0, b1;
-    SLOAD32(a0, a1, M);
-#pragma unroll
-    for (int j = 0; j < NJ; j += 2) {
-        SWAIT32(a0, a1);
-        SLOAD32(b0, b1, M + (j + 1) * 32);
-        xand_row(acc, v[j], a0, a1);
-        SWAIT32(b0, b1);
-        if (j + 2 < NJ) SLOAD32(a0, a1, M + (j + 2) * 32);
-        xand_row(acc, v[j + 1], b0, b1);
-    }
-}
-
-// touch the 64-B line at a (one line per lane) with a vector load whose result is never used. The loads are invisible to
-// the compiler's vmcnt bookkeeping: only issue them where no compiler-generated global load is in flight, keep
-// `pf` (the one destination register) alive, and drain before anything else uses vector memory.
-__device__ __forceinline__ void mask_prefetch(uint32_t &pf, const uint32_t *a) {
-    asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(a) : "memory");
-}
-__device__ __forceinline__ void mask_prefetch_drain(uint32_t &pf) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf)::"memory"); }
 
 // One intra-word level with its masks read from LDS as VGPR operands (ds_read_b128, same address in every lane): no
 // scalar-memory stream, whose two rows in flight cannot cover the latency of a table that does not fit any cache.
@@ -1447,20 +1403,6 @@ __device__ __forceinline__ void mask_prefetch_drain(uint32_t &pf) { asm volatile
 // 384 mask words per (value word, level) instead of 512 (k_build_lowmasks), + ~90 plain VALU ops that the LDS bound hides.
 #define LOW_BLK_WORDS 384  // 96 uint4: set 1 = M[4 j + kq], j < 16; set 2 = M[64 + 4 j' + kq], j' < 8
 #define AMAT_WORDS 768     // per value word: A[16][16] | X[16][16] | (A+B)[16][16] of the FFT(a) values (k_build_amat)
-template <int NJ>
-__device__ __forceinline__ void apply_masks16_lds(uint32_t acc[16], const uint32_t *v, const uint4 *M) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-#pragma unroll
-        for (int kq = 0; kq < 4; kq++) {
-            const uint4 m = M[j * 4 + kq];
-            acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
-            acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
-            acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
-            acc[4 * kq + 3] = XAND(acc[4 * kq + 3], v[j], m.w);
-        }
-    }
-}
 // acc ^= B v for the N x N block B = rows K0.., columns J0.. of a mask set M[4 j + k / 4] (16 output planes per j) whose
 // matrix (both packed halves, if packed) is that of GF(2^N) elements: Karatsuba down to 4 x 4 on the SAME table,
 // [[a, x], [b, a + b]] in blocks; the b blocks are never read: 36 broadcast reads per 16 x 16 block instead of 64
