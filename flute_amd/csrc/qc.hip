@@ -1856,34 +1856,10 @@ __device__ __forceinline__ void low_word_levels(uint32_t *lds, const tile_desc &
     }
 }
 
-// K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
-// pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
-// Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
-// NVW = value words per tile = 2^(d.nb - 5) = waves per workgroup (one value word per wave in the intra-word part, one
-// work item per wave in the word levels): 16 for m >= 25, fewer for the small transforms (m = 21: a single wave).
+// the intra-word part of the low kernel: wave w takes value word w of the tile (see k_fft_low)
 template <int MODE, int NVW>
-__global__ void __launch_bounds__(64 * NVW)
-    k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ LM,
-              const uint32_t *__restrict__ Amat) {
-    constexpr int NBK = NVW == 16 ? 9 : NVW == 8 ? 8 : NVW == 4 ? 7 : NVW == 2 ? 6 : 5;
-    __shared__ uint32_t lds[32 * NVW * TL_ROWS];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the two row halves of a tile read the same 14 KiB of masks per value word: they go to workgroups b and b + 8, which
-    // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
-    // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
-    uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
-    if (d.rhalves == 1) {
-        rh = 0, o = blockIdx.x;
-    } else if (gridDim.x % 16 == 0) {
-        rh = (blockIdx.x >> 3) & 1;
-        o = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
-    }
-    const uint32_t base_w = tile_base(d, o);
-    const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
-    tile_load<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
-    __syncthreads();
-    if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
+__device__ __forceinline__ void low_intra(uint32_t *lds, const uint32_t *__restrict__ LM, const uint32_t *__restrict__ Amat,
+                                          uint32_t o, uint32_t nvw, uint32_t wave, uint32_t lane) {
     for (uint32_t vi = wave; vi < nvw; vi += NVW) {
         uint32_t *p = lds + (vi << 5) * TL_ROWS + lane;
         const uint64_t vw = (uint64_t)o * nvw + vi;  // wave-uniform
@@ -1932,9 +1908,86 @@ __global__ void __launch_bounds__(64 * NVW)
 #pragma unroll
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
     }
+}
+
+// K5: the lowest word levels (those of the tile) + the intra-word levels, forward; MODE 1 continues with the
+// pointwise multiply by FFT(a) and the same levels inverse. MODE 0 is used once, for FFT(a) itself.
+// Tile = 5 plane bits + the lowest (up to 4) word bits: up to 16 value words x 32 planes x 64 rows = 128 KiB.
+// NVW = value words per tile = 2^(d.nb - 5) = waves per workgroup (one value word per wave in the intra-word part, one
+// work item per wave in the word levels): 16 for m >= 25, fewer for the small transforms (m = 21: a single wave).
+template <int MODE, int NVW>
+__global__ void __launch_bounds__(64 * NVW)
+    k_fft_low(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ LM,
+              const uint32_t *__restrict__ Amat) {
+    constexpr int NBK = NVW == 16 ? 9 : NVW == 8 ? 8 : NVW == 4 ? 7 : NVW == 2 ? 6 : 5;
+    __shared__ uint32_t lds[32 * NVW * TL_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the two row halves of a tile read the same 14 KiB of masks per value word: they go to workgroups b and b + 8, which
+    // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
+    // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
+    uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
+    if (d.rhalves == 1) {
+        rh = 0, o = blockIdx.x;
+    } else if (gridDim.x % 16 == 0) {
+        rh = (blockIdx.x >> 3) & 1;
+        o = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
+    }
+    const uint32_t base_w = tile_base(d, o);
+    const uint32_t nvw = (QC_EXP & 2) ? 0 : 1u << (d.nb - 5);  // value words in the tile
+    tile_load<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
+    __syncthreads();
+    if (!(QC_EXP & 1)) low_word_levels<false>(lds, d, base_w, TW, wave, lane);
+    low_intra<MODE, NVW>(lds, LM, Amat, o, nvw, wave, lane);
     __syncthreads();
     if (MODE == 1 && !(QC_EXP & 1)) low_word_levels<true>(lds, d, base_w, TW, wave, lane);
     tile_store<NBK, NVW>(lds, Z, d, base_w, rh, wave, lane);
+}
+
+// The same kernel, persistent, for the full-size tile (MODE 1, 16 value words, one workgroup per CU): the next tile is
+// fetched into registers (32 per thread) when the intra-word part, which needs the registers, is over, travels during
+// the inverse word levels, and is put into LDS after this tile's stores were issued -- load and store phases (0.23 of
+// 1.4 ms per launch) no longer leave the CU idle. idx -> (rh, o) as above with idx in place of blockIdx.x: workgroups
+// b and b ^ 8 (same XCD) walk the two row halves of the same tiles side by side.
+__global__ void __launch_bounds__(1024)
+    k_fft_low_p(uint32_t *__restrict__ Z, tile_desc d, const uint32_t *__restrict__ TW, const uint32_t *__restrict__ LM,
+                const uint32_t *__restrict__ Amat, uint32_t ntiles) {
+    __shared__ uint32_t lds[32 * 16 * TL_ROWS];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto map = [&](uint32_t idx, uint32_t &rh, uint32_t &o) {
+        rh = idx & 1, o = idx >> 1;
+        if (d.rhalves == 1) {
+            rh = 0, o = idx;
+        } else if (ntiles % 16 == 0) {
+            rh = (idx >> 3) & 1;
+            o = ((idx >> 4) << 3) | (idx & 7);
+        }
+    };
+    uint32_t idx = blockIdx.x;
+    if (idx >= ntiles) return;
+    uint32_t rh, o;
+    map(idx, rh, o);
+    typename tile_regs<32>::type v = tile_fetch<9>(Z, d, tile_base(d, o), rh, wave, lane);
+#pragma unroll 1
+    for (; idx < ntiles; idx += gridDim.x) {
+        map(idx, rh, o);
+        const uint32_t base_w = tile_base(d, o);
+        tile_put<9>(lds, v, d, wave, lane);
+        __syncthreads();
+        low_word_levels<false>(lds, d, base_w, TW, wave, lane);
+        low_intra<1, 16>(lds, LM, Amat, o, 16u, wave, lane);
+        __syncthreads();
+        {
+            const uint32_t nidx = idx + gridDim.x < ntiles ? idx + gridDim.x : idx;
+            uint32_t nrh, no;
+            map(nidx, nrh, no);
+            v = tile_fetch<9>(Z, d, tile_base(d, no), nrh, wave, lane);
+        }
+        low_word_levels<true>(lds, d, base_w, TW, wave, lane);
+        tile_store<9, 16>(lds, Z, d, base_w, rh, wave, lane);
+        __syncthreads();
+    }
 }
 
 template <int MODE>
@@ -1945,7 +1998,13 @@ static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
         case 6: hipLaunchKernelGGL((k_fft_low<MODE, 2>), g, dim3(128), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
         case 7: hipLaunchKernelGGL((k_fft_low<MODE, 4>), g, dim3(256), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
         case 8: hipLaunchKernelGGL((k_fft_low<MODE, 8>), g, dim3(512), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
-        default: hipLaunchKernelGGL((k_fft_low<MODE, 16>), g, dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        default:
+            if (MODE == 1 && !QC_EXP && g.x > c->num_cus && !(c->opts & SOT_OPT_NO_TOP)) {
+                hipLaunchKernelGGL(k_fft_low_p, dim3(c->num_cus), dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat, g.x);
+                break;
+            }
+            hipLaunchKernelGGL((k_fft_low<MODE, 16>), g, dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat);
+            break;
     }
 }
 

@@ -28,7 +28,7 @@ def short(name):
 # 537 MB and the counter shows 277 MB (profiles/r2_e_pmc.csv), i.e. 1/2 again. (k_conv_tile, the fallback for
 # SOT_NO_TOP, keeps the old order.)
 FETCH_FACTOR_EXACT = ("k_conv_tile",)
-QC_PREFIXES = ("k_qc_load", "k_conv_", "k_top", "k_mid", "k_fft_low<1", "k_tile_fft", "k_qc_finish", "k_clear_lsb",
+QC_PREFIXES = ("k_qc_load", "k_conv_", "k_top", "k_mid", "k_fft_low<1", "k_fft_low_p", "k_tile_fft", "k_qc_finish", "k_clear_lsb",
                "k_sparse_choice", "k_set_points")
 GGM_PREFIXES = ("k_roots", "k_ggm_", "k_sender_treegrp", "k_recv_")
 
@@ -74,7 +74,8 @@ def main():
 
 
     # profiles/pmc_latest.json: what bench.py reports as roofline.traffic (dominant kernel, per launch)
-    dom = next((k for k in pmc if k.startswith("k_fft_low<1")), "k_fft_low<1>")
+    # the dominant kernel: the persistent form of the low kernel (n >= 2^24), else the plain one
+    dom = next((k for k in pmc if k.startswith("k_fft_low_p")), None) or next((k for k in pmc if k.startswith("k_fft_low<1")), "k_fft_low<1>")
     if dom in pmc and "FETCH_SIZE" in pmc[dom] and "WRITE_SIZE" in pmc[dom]:
         import json
         e = pmc[dom]
