@@ -980,6 +980,36 @@ __device__ __forceinline__ void tw_rows(const uint32_t *__restrict__ TW, uint32_
     }
 }
 
+// acc ^= M u for the N x N block M = rows[K0 + k] bits J0 + j (k, j < N) of a twiddle matrix, where M is the matrix of an
+// element of GF(2^N): over the tower GF(2^N) = GF(2^(N/2))[t], t^2 = t + zeta, M = [[a, x], [b, a + b]] in blocks, so
+//   acc_lo ^= a u_lo ^ x u_hi,   acc_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo
+// three half-size products instead of four, recursively down to 2 x 2 (measured: 3.44 -> 3.28 -> 3.22 ms per step for bases 8, 4, 2; scalar masks: a v_bitop3 with an SGPR operand
+// costs 5 cycles, a plain v_xor 3, so trading 7 XANDs of 16 for 3-4 XORs pays twice over).
+#ifndef KARA_BASE
+#define KARA_BASE 2
+#endif
+template <int N, int K0, int J0>
+__device__ __forceinline__ void kara_acc(uint32_t *acc, const uint32_t *u, const uint32_t *rows) {
+    if constexpr (N <= KARA_BASE) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+#pragma unroll
+            for (int k = 0; k < N; k++) acc[k] = XAND(acc[k], u[j], 0u - ((rows[K0 + k] >> (J0 + j)) & 1u));
+        }
+    } else {
+        constexpr int H = N / 2;
+        uint32_t t1[H], sm[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = u[k] ^ u[k + H];
+        kara_acc<H, K0, J0>(t1, u, rows);
+        kara_acc<H, K0, J0 + H>(acc, u + H, rows);
+        kara_acc<H, K0 + H, J0 + H>(acc + H, sm, rows);
+#pragma unroll
+        for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tiles. A workgroup gathers 2^nb granules (x 64 rows) whose word indices differ in the nb bits pos[0..nb),
 // runs some butterfly levels on them in LDS and scatters them back. Tile bit j <-> word-index bit pos[j]; the
@@ -1150,11 +1180,12 @@ __device__ __forceinline__ void bfly_item(const uint32_t *lds, uint32_t xs, uint
     uint32_t acc[NO];
 #pragma unroll
     for (int kk = 0; kk < NO; kk++) acc[kk] = lds[(xs + c0 + kk) * TL_ROWS + lane];
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-#pragma unroll
-        for (int kk = 0; kk < NO; kk++) acc[kk] = XAND(acc[kk], y[j], 0u - ((rows[kk] >> j) & 1u));
-        __builtin_amdgcn_sched_barrier(0);
+    // the NO x K strip in NO x NO blocks, each the matrix of a GF(2^NO) element: kara_acc
+    kara_acc<NO, 0, 0>(acc, y, rows);
+    if constexpr (K >= 16) kara_acc<NO, 0, 8>(acc, y + 8, rows);
+    if constexpr (K >= 32) {
+        kara_acc<NO, 0, 16>(acc, y + 16, rows);
+        kara_acc<NO, 0, 24>(acc, y + 24, rows);
     }
 #pragma unroll
     for (int kk = 0; kk < NO; kk++) xn[kk] = acc[kk];
@@ -1309,16 +1340,16 @@ __device__ __forceinline__ void w32_item(const uint32_t *l0, const uint32_t *l1,
         xn0[kk] = l0[(xs + c0 + kk) * TL_ROWS + lane];
         xn1[kk] = l1[(xs + c0 + kk) * TL_ROWS + lane];
     }
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-#pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
-            const uint32_t mk = 0u - ((rows[kk] >> j) & 1u);
-            xn0[kk] = XAND(xn0[kk], y0[j], mk);
-            xn1[kk] = XAND(xn1[kk], y1[j], mk);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    // the 8 x 32 strip is four 8 x 8 blocks, each the matrix of a GF(2^8) element: kara_acc (the scalar masks of the two
+    // row halves are the same expressions and are formed once)
+    kara_acc<8, 0, 0>(xn0, y0, rows);
+    kara_acc<8, 0, 0>(xn1, y1, rows);
+    kara_acc<8, 0, 8>(xn0, y0 + 8, rows);
+    kara_acc<8, 0, 8>(xn1, y1 + 8, rows);
+    kara_acc<8, 0, 16>(xn0, y0 + 16, rows);
+    kara_acc<8, 0, 16>(xn1, y1 + 16, rows);
+    kara_acc<8, 0, 24>(xn0, y0 + 24, rows);
+    kara_acc<8, 0, 24>(xn1, y1 + 24, rows);
     // y chunk: re-read (dynamic register indexing would spill)
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) {
@@ -1762,36 +1793,6 @@ __global__ void k_build_midmasks(tile_desc d, uint32_t mask_hi, uint32_t rmin, u
     uint32_t rows[16];
     tw_rows<16>(TW, q, 0, rows);
     for (uint32_t k = 0; k < 16; k++) MT[(uint64_t)idx * 16 + k] = 0u - ((rows[k] >> j) & 1u);
-}
-
-// acc ^= M u for the N x N block M = rows[K0 + k] bits J0 + j (k, j < N) of a twiddle matrix, where M is the matrix of an
-// element of GF(2^N): over the tower GF(2^N) = GF(2^(N/2))[t], t^2 = t + zeta, M = [[a, x], [b, a + b]] in blocks, so
-//   acc_lo ^= a u_lo ^ x u_hi,   acc_hi ^= (a + b)(u_lo ^ u_hi) ^ a u_lo
-// three half-size products instead of four, recursively down to 2 x 2 (measured: 3.44 -> 3.28 -> 3.22 ms per step for bases 8, 4, 2; scalar masks: a v_bitop3 with an SGPR operand
-// costs 5 cycles, a plain v_xor 3, so trading 7 XANDs of 16 for 3-4 XORs pays twice over).
-#ifndef KARA_BASE
-#define KARA_BASE 2
-#endif
-template <int N, int K0, int J0>
-__device__ __forceinline__ void kara_acc(uint32_t *acc, const uint32_t *u, const uint32_t *rows) {
-    if constexpr (N <= KARA_BASE) {
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-#pragma unroll
-            for (int k = 0; k < N; k++) acc[k] = XAND(acc[k], u[j], 0u - ((rows[K0 + k] >> (J0 + j)) & 1u));
-        }
-    } else {
-        constexpr int H = N / 2;
-        uint32_t t1[H], sm[H];
-#pragma unroll
-        for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = u[k] ^ u[k + H];
-        kara_acc<H, K0, J0>(t1, u, rows);
-        kara_acc<H, K0, J0 + H>(acc, u + H, rows);
-        kara_acc<H, K0 + H, J0 + H>(acc + H, sm, rows);
-#pragma unroll
-        for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // the 32-plane word levels of the low tile (slot = lv * 32 + plane, lv bit b <-> level m - 4 - nl + b): one wave per
