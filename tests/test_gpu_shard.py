@@ -98,7 +98,8 @@ CASES = [(1000, 2, 2, False), (1000, 2, 4, False), (1000, 2, 8, False), (1000, 1
          (1 << 20, 4, 4, True), (3 * 2 ** 20 + 12345, 7, 4, False),
          # the row-half / slice skipping of 4 and 8 ranks on every low-kernel template (m = 22 ... 24) and a ragged size
          (100003, 3, 8, True), (1 << 21, 4, 4, False), (1 << 22, 4, 8, False), (1 << 23, 4, 4, False),
-         (3 * 2 ** 20 + 12345, 5, 8, False)]
+         (3 * 2 ** 20 + 12345, 5, 8, False),
+         (1 << 24, 4, 4, False)]  # m = 25: the persistent low kernel (k_fft_low_p) on one row half (64 live rows)
 
 
 @pytest.mark.parametrize("n,T,world,replicated", CASES)
