@@ -1543,11 +1543,7 @@ __device__ __forceinline__ void reg_bfly(uint32_t x[K], uint32_t y[K], const uin
 #pragma unroll
         for (int k = 0; k < K; k++) y[k] ^= x[k];
     }
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-#pragma unroll
-        for (int k = 0; k < K; k++) x[k] = XAND(x[k], y[j], 0u - ((rows[k] >> j) & 1u));
-    }
+    kara_acc<K, 0, 0>(x, y, rows);
     if (!INV && !pruned) {
 #pragma unroll
         for (int k = 0; k < K; k++) y[k] ^= x[k];
