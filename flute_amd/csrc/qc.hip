@@ -1920,7 +1920,7 @@ __global__ void __launch_bounds__(64 * NVW)
     __shared__ uint32_t lds[32 * NVW * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the two row halves of a tile read the same 14 KiB of masks per value word: they go to workgroups b and b + 8, which
+    // the two row halves of a tile read the same 18 KiB of mask blocks per value word (12 blocks of 1.5 KiB): they go to workgroups b and b + 8, which
     // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
     // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
     uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
