@@ -32,7 +32,7 @@
 #define QC_EXP 0
 #endif
 #ifndef LOW_RING
-#define LOW_RING 5  // k_fft_low: mask blocks (1.5 KiB) in a value word's 8 KiB ring, LOW_RING - 1 of them loaded ahead
+#define LOW_RING 8  // k_fft_low: mask blocks (<= 960 B) in a value word's 8 KiB ring, LOW_RING - 1 of them loaded ahead
 #endif
 
 static __device__ const uint32_t d_BETA[32] = {
@@ -1432,8 +1432,28 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 //     out_lo = A y_lo + X y_hi                    (set 1: 16 x 16 mask words, y_lo at the x positions, y_hi at the y positions)
 //     out_hi = (A + B) s + A y_lo                 (set 2:  8 x 16 mask words, s_j at the x positions, s_(j+8) at the y positions)
 // 384 mask words per (value word, level) instead of 512 (k_build_lowmasks), + ~90 plain VALU ops that the LDS bound hides.
-#define LOW_BLK_WORDS 384  // 96 uint4: set 1 = M[4 j + kq], j < 16; set 2 = M[64 + 4 j' + kq], j' < 8
-#define AMAT_WORDS 768     // per value word: A[16][16] | X[16][16] | (A+B)[16][16] of the FFT(a) values (k_build_amat)
+// Plain layout of a block: 96 uint4 = 384 words, set 1 = M[4 j + kq], j < 16; set 2 = M[64 + 4 j' + kq], j' < 8 (levels);
+// A | X rows 0..7 and X rows 8..15 | A + B (the two blocks of Amat). The recursion below never reads the b blocks, so
+// the tables in memory hold only the uint4 that are read, in plain order (d_LOWCMAP[type][plain uint4] = packed index or
+// -1; type 0 = level block: 60 of 96, 1 / 2 = first / second Amat block: 48 and 60): 37 % less mask traffic, one
+// 16-byte load per lane and block.
+#define LOW_BLK_PLAIN 384
+#define LOW_BLK_WORDS 240  // packed words of a level block
+#define AMAT_PLAIN 768
+#define AMAT_B0_WORDS 192  // packed words of the first Amat block
+#define AMAT_WORDS 432     // packed words per value word
+#define LOW_SLOT 60        // uint4 per ring slot
+static __device__ const int8_t d_LOWCMAP[3][96] = {
+    {0, -1, -1, -1, 1, -1, -1, -1, 2, -1, -1, -1, 3, -1, -1, -1, 4, 5, -1, -1, 6, 7, -1, -1, 8, 9, -1, -1, 10, 11, -1, -1, 12, -1, 13, -1, 14, -1, 15, -1, 16, -1, 17, -1, 18, -1, 19, -1, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, -1, 37, -1, 38, -1, 39, -1, 40, -1, 41, -1, 42, -1, 43, -1, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59},
+    {0, -1, -1, -1, 1, -1, -1, -1, 2, -1, -1, -1, 3, -1, -1, -1, 4, 5, -1, -1, 6, 7, -1, -1, 8, 9, -1, -1, 10, 11, -1, -1, 12, -1, 13, -1, 14, -1, 15, -1, 16, -1, 17, -1, 18, -1, 19, -1, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, -1, -1, -1, 37, -1, -1, -1, 38, -1, -1, -1, 39, -1, -1, -1, 40, 41, -1, -1, 42, 43, -1, -1, 44, 45, -1, -1, 46, 47, -1, -1},
+    {0, -1, 1, -1, 2, -1, 3, -1, 4, -1, 5, -1, 6, -1, 7, -1, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, -1, -1, -1, 25, -1, -1, -1, 26, -1, -1, -1, 27, -1, -1, -1, 28, 29, -1, -1, 30, 31, -1, -1, 32, 33, -1, -1, 34, 35, -1, -1, 36, -1, 37, -1, 38, -1, 39, -1, 40, -1, 41, -1, 42, -1, 43, -1, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59}};
+struct IdMap {
+    static __device__ __forceinline__ int at(int i) { return i; }
+};
+template <int TYPE, int OFF>
+struct LowMap {
+    static __device__ __forceinline__ int at(int i) { return d_LOWCMAP[TYPE][OFF + i]; }
+};
 // acc ^= B v for the N x N block B = rows K0.., columns J0.. of a mask set M[4 j + k / 4] (16 output planes per j) whose
 // matrix (both packed halves, if packed) is that of GF(2^N) elements: Karatsuba down to 4 x 4 on the SAME table,
 // [[a, x], [b, a + b]] in blocks; the b blocks are never read: 36 broadcast reads per 16 x 16 block instead of 64
@@ -1441,14 +1461,14 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 #ifndef KARA_LDS_BASE
 #define KARA_LDS_BASE 4
 #endif
-template <int N, int K0, int J0, int BASE = KARA_LDS_BASE>
+template <int N, int K0, int J0, int BASE = KARA_LDS_BASE, class MAP = IdMap>
 __device__ __forceinline__ void kara_lds(uint32_t *acc, const uint32_t *v, const uint4 *M) {
     if constexpr (N <= BASE) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
 #pragma unroll
             for (int kq = 0; kq < N / 4; kq++) {
-                const uint4 m = M[(J0 + j) * 4 + K0 / 4 + kq];
+                const uint4 m = M[MAP::at((J0 + j) * 4 + K0 / 4 + kq)];
                 acc[4 * kq + 0] = XAND(acc[4 * kq + 0], v[j], m.x);
                 acc[4 * kq + 1] = XAND(acc[4 * kq + 1], v[j], m.y);
                 acc[4 * kq + 2] = XAND(acc[4 * kq + 2], v[j], m.z);
@@ -1460,9 +1480,9 @@ __device__ __forceinline__ void kara_lds(uint32_t *acc, const uint32_t *v, const
         uint32_t t1[H], sm[H];
 #pragma unroll
         for (int k = 0; k < H; k++) t1[k] = 0, sm[k] = v[k] ^ v[k + H];
-        kara_lds<H, K0, J0, BASE>(t1, v, M);
-        kara_lds<H, K0, J0 + H, BASE>(acc, v + H, M);
-        kara_lds<H, K0 + H, J0 + H, BASE>(acc + H, sm, M);
+        kara_lds<H, K0, J0, BASE, MAP>(t1, v, M);
+        kara_lds<H, K0, J0 + H, BASE, MAP>(acc, v + H, M);
+        kara_lds<H, K0 + H, J0 + H, BASE, MAP>(acc + H, sm, M);
 #pragma unroll
         for (int k = 0; k < H; k++) acc[k] ^= t1[k], acc[k + H] ^= t1[k];
     }
@@ -1481,7 +1501,7 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
     uint32_t a1[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a1[k] = 0;
-    kara_lds<16, 0, 0>(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
+    kara_lds<16, 0, 0, KARA_LDS_BASE, LowMap<0, 0>>(a1, P, M);  // x positions: A y_lo, y positions: X y_hi
     uint32_t S[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) S[j] = BFI(P[j] ^ (P[j] >> SH), P[j + 8] ^ (P[j + 8] << SH), A);
@@ -1489,8 +1509,8 @@ __device__ __forceinline__ void low_level_lds(uint32_t W[32], const uint4 *M) {
 #pragma unroll
     for (int k = 0; k < 16; k++) a3[k] = 0;
     // x + y positions: (A + B) s; per 8 output planes the two packed 8 x 8 halves are matrices of GF(2^8) elements
-    kara_lds<8, 0, 0>(a3, S, M + 64);
-    kara_lds<8, 8, 0>(a3 + 8, S, M + 64);
+    kara_lds<8, 0, 0, KARA_LDS_BASE, LowMap<0, 64>>(a3, S, M);
+    kara_lds<8, 8, 0, KARA_LDS_BASE, LowMap<0, 64>>(a3 + 8, S, M);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         W[k] = XAND(W[k], a1[k] ^ (a1[k] >> SH), A);
@@ -1508,19 +1528,19 @@ __device__ __forceinline__ void amat_block0(const uint32_t W[32], const uint4 *M
     for (int k = 0; k < 16; k++) t1[k] = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) tt[k] = 0;
-    kara_lds<16, 0, 0>(t1, W, M);          // A w_lo
-    kara_lds<8, 0, 0>(tt, W + 16, M + 64);  // the a block of X times the low half of w_hi
+    kara_lds<16, 0, 0, KARA_LDS_BASE, LowMap<1, 0>>(t1, W, M);         // A w_lo
+    kara_lds<8, 0, 0, KARA_LDS_BASE, LowMap<1, 64>>(tt, W + 16, M);    // the a block of X times the low half of w_hi
 }
 __device__ __forceinline__ void amat_block1(uint32_t W[32], const uint4 *M, const uint32_t t1[16], const uint32_t tt[8]) {
     uint32_t t2[16], sx[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) t2[k] = tt[k], t2[k + 8] = tt[k], sx[k] = W[16 + k] ^ W[24 + k];
-    kara_lds<8, 0, 0>(t2, W + 24, M);   // x block of X
-    kara_lds<8, 8, 0>(t2 + 8, sx, M);   // (a + b) block of X
+    kara_lds<8, 0, 0, KARA_LDS_BASE, LowMap<2, 0>>(t2, W + 24, M);   // x block of X
+    kara_lds<8, 8, 0, KARA_LDS_BASE, LowMap<2, 0>>(t2 + 8, sx, M);   // (a + b) block of X
     uint32_t sm[16], t3[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[j] = W[j] ^ W[j + 16], t3[j] = 0;
-    kara_lds<16, 0, 0>(t3, sm, M + 32);  // (A + B)(w_lo + w_hi)
+    kara_lds<16, 0, 0, KARA_LDS_BASE, LowMap<2, 32>>(t3, sm, M);  // (A + B)(w_lo + w_hi)
 #pragma unroll
     for (int k = 0; k < 16; k++) W[k] = t1[k] ^ t2[k], W[k + 16] = t3[k] ^ t1[k];
 }
@@ -1863,29 +1883,29 @@ __device__ __forceinline__ void low_intra(uint32_t *lds, const uint32_t *__restr
         const uint32_t *L = LM + vw * (5 * LOW_BLK_WORDS);
         const uint32_t *A = Amat + vw * AMAT_WORDS;
         // While W is in registers the 8 KiB of this value word in LDS are free and private to the wave: a ring of
-        // LOW_RING mask blocks of 1.5 KiB, filled LOW_RING - 1 blocks ahead with plain vector loads (16 B per lane, and
-        // 16 B more in the lower half of the wave, per block). Blocks in the order they are consumed: forward levels
+        // LOW_RING mask blocks of at most 960 B, filled LOW_RING - 1 blocks ahead with plain vector loads (16 B per lane and
+        // block). Blocks in the order they are consumed: forward levels
         // 4..0, [the two blocks of Amat, inverse levels 0..4].
-        constexpr int NBLK = MODE == 1 ? 12 : 5, AH = LOW_RING - 1;
+        constexpr int NBLK = MODE == 1 ? 12 : 5, AH = LOW_RING - 1 < NBLK ? LOW_RING - 1 : NBLK;
         uint4 *R = (uint4 *)(lds + (vi << 5) * TL_ROWS);
-        const uint32_t l2 = 64 + (lane & 31);
+        const uint32_t li = lane < LOW_SLOT ? lane : LOW_SLOT - 1;  // a block is at most 60 uint4: one per lane
         auto src = [&](int b) {
-            return (const uint4 *)(lowblk_is_amat(b) ? A + (b - 5) * LOW_BLK_WORDS : L + lowblk_level(b) * LOW_BLK_WORDS);
+            return (const uint4 *)(lowblk_is_amat(b) ? A + (b - 5) * AMAT_B0_WORDS : L + lowblk_level(b) * LOW_BLK_WORDS);
         };
-        uint4 s0[AH], s1[AH];
+        uint4 s0[AH];
 #pragma unroll
-        for (int b = 0; b < AH; b++) s0[b] = src(b)[lane], s1[b] = src(b)[l2];
+        for (int b = 0; b < AH; b++) s0[b] = src(b)[li];
         uint32_t W[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) W[k] = p[k * TL_ROWS];
 #pragma unroll
-        for (int b = 0; b < AH; b++) R[b * 96 + lane] = s0[b], R[b * 96 + l2] = s1[b];
+        for (int b = 0; b < AH; b++) R[b * LOW_SLOT + li] = s0[b];
         uint32_t t1[16], t2[8];
 #pragma unroll
         for (int b = 0; b < NBLK; b++) {
-            uint4 n0, n1;
-            if (b + AH < NBLK) n0 = src(b + AH)[lane], n1 = src(b + AH)[l2];
-            const uint4 *M = R + (b % LOW_RING) * 96;
+            uint4 n0;
+            if (b + AH < NBLK) n0 = src(b + AH)[li];
+            const uint4 *M = R + (b % LOW_RING) * LOW_SLOT;
             switch (b) {
                 case 0: low_level_lds<4, false>(W, M); break;
                 case 1: low_level_lds<3, false>(W, M); break;
@@ -1900,7 +1920,7 @@ __device__ __forceinline__ void low_intra(uint32_t *lds, const uint32_t *__restr
                 case 10: low_level_lds<3, true>(W, M); break;
                 default: low_level_lds<4, true>(W, M); break;
             }
-            if (b + AH < NBLK) R[((b + AH) % LOW_RING) * 96 + lane] = n0, R[((b + AH) % LOW_RING) * 96 + l2] = n1;
+            if (b + AH < NBLK) R[((b + AH) % LOW_RING) * LOW_SLOT + li] = n0;
         }
 #pragma unroll
         for (int k = 0; k < 32; k++) p[k * TL_ROWS] = W[k];
@@ -1920,7 +1940,7 @@ __global__ void __launch_bounds__(64 * NVW)
     __shared__ uint32_t lds[32 * NVW * TL_ROWS];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the two row halves of a tile read the same 18 KiB of mask blocks per value word (12 blocks of 1.5 KiB): they go to workgroups b and b + 8, which
+    // the two row halves of a tile read the same 11 KiB of mask blocks per value word (12 blocks of up to 960 B): they go to workgroups b and b + 8, which
     // run on the same XCD (workgroup b -> XCD b % 8) next to each other in launch order, so the second finds them in
     // that XCD's L2 (with rh = b & 1 they sat on two XCDs and every mask line came from HBM twice)
     uint32_t rh = blockIdx.x & 1, o = blockIdx.x >> 1;
@@ -2011,10 +2031,12 @@ static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
 //   t >= 256: j' = (t - 256) / 16, k: bit 16 + j' of row k + 16 at x positions, bit 24 + j' at y positions (A + B)
 __global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__restrict__ TW, uint32_t *__restrict__ LM) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nvals * 5 * LOW_BLK_WORDS) return;
-    const uint32_t t = (uint32_t)(idx % LOW_BLK_WORDS);
-    const uint32_t li = (uint32_t)((idx / LOW_BLK_WORDS) % 5);
-    const uint32_t vw = (uint32_t)(idx / (5 * LOW_BLK_WORDS));
+    if (idx >= nvals * 5 * LOW_BLK_PLAIN) return;  // one thread per word of the plain layout; unread words are dropped
+    const uint32_t t = (uint32_t)(idx % LOW_BLK_PLAIN);
+    const uint32_t li = (uint32_t)((idx / LOW_BLK_PLAIN) % 5);
+    const uint32_t vw = (uint32_t)(idx / (5 * LOW_BLK_PLAIN));
+    const int cu = d_LOWCMAP[0][t >> 2];
+    if (cu < 0) return;
     const bool set2 = t >= 256;
     const uint32_t j = set2 ? (t - 256) >> 4 : t >> 4, k = (t & 15) + (set2 ? 16 : 0);
     const uint32_t nvw = 1u << (d.nb - 5);
@@ -2030,7 +2052,7 @@ __global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__
         const uint32_t jj = set2 ? 16 + j + 8 * ypos : j + 16 * ypos;
         mask |= ((R >> jj) & 1u) << p;
     }
-    LM[idx] = mask;
+    LM[((uint64_t)vw * 5 + li) * LOW_BLK_WORDS + (uint32_t)cu * 4 + (t & 3u)] = mask;
 }
 
 // Amat[(o * nvw + vi) * 768 + t] bit p = entry (k, j) of the matrix 'multiply by the FFT(a) value at position p of value
@@ -2038,8 +2060,11 @@ __global__ void k_build_lowmasks(tile_desc d, uint64_t nvals, const uint32_t *__
 // (t % 16, 16 + (t - 256) / 16); t >= 512: (16 + t % 16, 16 + (t - 512) / 16). See amat_block0/1.
 __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64_t nvals, uint32_t *__restrict__ Amat) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nvals * AMAT_WORDS) return;
-    const uint32_t vw = (uint32_t)(idx / AMAT_WORDS), t = (uint32_t)(idx % AMAT_WORDS);
+    if (idx >= nvals * AMAT_PLAIN) return;  // one thread per word of the plain layout (two blocks of 96 uint4)
+    const uint32_t vw = (uint32_t)(idx / AMAT_PLAIN), t = (uint32_t)(idx % AMAT_PLAIN);
+    const uint32_t blk = t >= LOW_BLK_PLAIN, tb = t - blk * LOW_BLK_PLAIN;
+    const int cu = d_LOWCMAP[1 + blk][tb >> 2];
+    if (cu < 0) return;
     const uint32_t set = t >> 8;
     const uint32_t j = ((t & 255u) >> 4) + (set ? 16 : 0), k = (t & 15u) + (set == 2 ? 16 : 0);
     const uint32_t nvw = 1u << (d.nb - 5);
@@ -2047,7 +2072,7 @@ __global__ void k_build_amat(const uint32_t *__restrict__ Z, tile_desc d, uint64
     uint32_t mm = 0;
     for (uint32_t tt = 0; tt < 32; tt++)
         if ((d_RTAB[tt * 32 + k] >> j) & 1) mm ^= Z[(uint64_t)(w | tile_word(d, tt)) * ROWS];
-    Amat[idx] = mm;
+    Amat[(uint64_t)vw * AMAT_WORDS + blk * AMAT_B0_WORDS + (uint32_t)cu * 4 + (tb & 3u)] = mm;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2695,10 +2720,10 @@ static int upload_a_and_transform(sot_ctx *c) {
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
-    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * LOW_BLK_WORDS, 256)), dim3(256), 0, c->stream, plan.low,
+    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * LOW_BLK_PLAIN, 256)), dim3(256), 0, c->stream, plan.low,
                        g.nw / 32, c->TW, c->LM);
     launch_low<0>(c, zb[cur], plan.low);
-    hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * AMAT_WORDS, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
+    hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * AMAT_PLAIN, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
                        g.nw / 32, c->Amat);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));

@@ -147,11 +147,11 @@ struct sot_ctx {
     uint32_t *Z0 = nullptr, *Z1 = nullptr;  // bit rows [word][128 rows], ping-pong (the transform runs in place)
     uint32_t rows_active = 128;             // bit rows that hold data (qc_set_rows_active)
     uint32_t *TW = nullptr, *TWC = nullptr; // twiddle matrix tables
-    uint32_t *LM = nullptr;                 // per value word packed twiddle masks of the intra-word levels [nw/32][5][384]
+    uint32_t *LM = nullptr;                 // per value word packed twiddle masks of the intra-word levels [nw/32][5][240] (packed: see d_LOWCMAP)
     uint32_t *MT1 = nullptr, *MT2 = nullptr; // twiddle masks of the 16-plane passes (levels 9..12 / 13..16)
     void *qc_plan = nullptr;                // fft_plan (qc.hip): tile descriptors of the passes
     uint32_t *up_list = nullptr;            // move lists of the whole-unit conversion phases
-    uint32_t *Amat = nullptr;               // per value word multiply-by-FFT(a) bit matrices [nw/32][768]
+    uint32_t *Amat = nullptr;               // per value word multiply-by-FFT(a) bit matrices [nw/32][432] (packed)
     uint32_t *a2 = nullptr;                 // a mod (x^P - 1), bit vector repeated twice (words)
     uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
     std::vector<uint32_t> a_hi_host;
