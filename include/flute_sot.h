@@ -217,7 +217,9 @@ int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
  * inputs as a row index; lam_out[inst][g]: this party's share of the output lambda (0/1). delta_share_out[inst][g] (0/1):
  * the bits of Msg::Delta; the public output is the XOR of both parties' (:145-165). NOTE: the reference's own AND-fold
  * (:1177-1188) starts from all-false and zeroes every term (its tests are #[ignore]d); this computes the protocol as
- * specified -- parity unpinned, checked against the plaintext LUT value instead (tests/test_gpu_lut_eval.py). */
+ * specified -- parity unpinned, checked against the plaintext LUT value instead (tests/test_gpu_lut_eval.py).
+ * The device copies of the template tables and of the per-item arrays live in `circ` and are grown on demand: calls
+ * with the same or a smaller batch allocate nothing. */
 int sot_lut_online_eval(sot_and_circ *circ, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
                         const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
                         const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id, uint8_t *delta_share_out);
