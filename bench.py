@@ -378,6 +378,8 @@ def roles_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
         print(json.dumps(out), flush=True)
     eng.close()
     dist.destroy_process_group()
+    if verified is False:  # a number from a wrong result is no number
+        raise SystemExit("bench.py: the joined MT words differ from the one-GPU context (sharded_equals_one_gpu = false)")
 
 
 def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
@@ -504,6 +506,8 @@ def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
         print(json.dumps(out), flush=True)
     eng.close()
     dist.destroy_process_group()
+    if verified is False:  # a number from a wrong result is no number
+        raise SystemExit("bench.py: the gathered MT words differ from the one-GPU context (sharded_equals_one_gpu = false)")
 
 
 def main():

@@ -17,6 +17,10 @@ pub const SOT_ENOMEM: c_int = -3;
 pub const SOT_ESTATE: c_int = -4;
 pub const SOT_ROLE_SENDER: c_int = 0;
 pub const SOT_ROLE_RECEIVER: c_int = 1;
+pub const SOT_OUT_B: c_int = 0;
+pub const SOT_OUT_A: c_int = 1;
+pub const SOT_OUT_SENDER_MSGS: c_int = 2;
+pub const SOT_OUT_RECEIVER_MSGS: c_int = 3;
 
 /// `sot_conf`: QuasiCyclicConf + PprfConfig (quasi_cyclic_encode.rs:156-233, pprf.rs:40-44)
 #[repr(C)]
@@ -91,6 +95,7 @@ extern "C" {
     pub fn sot_mt_bits(ctx: *mut SotCtx, delta: *const c_void, a_out: *mut u64, b_out: *mut u64, c_out: *mut u64) -> c_int;
     pub fn sot_mt_role_bits_to_device(ctx: *mut SotCtx, role: c_int, delta: *const c_void, dst_device: *mut c_void, dst_bytes: u64) -> c_int;
     pub fn sot_mt_bits_to_device(ctx: *mut SotCtx, dst_device: *mut c_void, dst_bytes: u64) -> c_int;
+    pub fn sot_blocks_to_device(ctx: *mut SotCtx, what: c_int, delta: *const c_void, dst_device: *mut c_void, dst_bytes: u64) -> c_int;
     pub fn sot_ctx_create_sharded(n: u64, scaler: u64, device: c_int, rank: u32, world: u32, ggm_replicated: c_int, out: *mut *mut SotCtx) -> c_int;
     pub fn sot_shard_info_get(ctx: *const SotCtx, out: *mut SotShardInfo) -> c_int;
     pub fn sot_shard_pack_leaves(ctx: *mut SotCtx, send_dev: *mut c_void) -> c_int;

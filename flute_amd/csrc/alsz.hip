@@ -90,8 +90,14 @@ struct sot_alsz_ctx {
     uint8_t *d_bc;    // [128]
     uint32_t *h_rks;  // pinned staging of the expanded keys
     uint64_t last_count, last_nj;
+    hipEvent_t done;  // recorded behind the last kernel of every call: what a consumer of d_U / d_out on another stream waits for
     std::mutex mu;
 };
+
+// live contexts, so that sot_alsz_ctx_send can order itself behind the context whose u-row matrix it is handed
+// (a different stream: without the wait the sender's kernel could read U before the receiver's kernel has written it)
+static std::mutex g_alsz_reg_mu;
+static std::vector<sot_alsz_ctx *> g_alsz_reg;
 
 static void alsz_free(sot_alsz_ctx *a) {
     if (!a) return;
@@ -100,6 +106,16 @@ static void alsz_free(sot_alsz_ctx *a) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (a->h_rks) (void)hipHostFree(a->h_rks);
+    {
+        std::lock_guard<std::mutex> lk(g_alsz_reg_mu);
+        for (size_t i = 0; i < g_alsz_reg.size(); i++)
+            if (g_alsz_reg[i] == a) {
+                g_alsz_reg.erase(g_alsz_reg.begin() + i);
+                break;
+            }
+    }
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    if (a->done) (void)hipEventDestroy(a->done);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }
@@ -114,8 +130,10 @@ extern "C" int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx 
     a->max_nj = (max_count + 127) / 128;
     a->last_count = a->last_nj = 0;
     a->stream = nullptr;
+    a->done = nullptr;
     a->d_rks = nullptr, a->d_ch = nullptr, a->d_U = nullptr, a->d_out = nullptr, a->d_bc = nullptr, a->h_rks = nullptr;
     const bool ok = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&a->done, hipEventDisableTiming) == hipSuccess &&
                     hipMalloc((void **)&a->d_rks, 256 * 44 * 4) == hipSuccess &&
                     hipMalloc((void **)&a->d_ch, a->max_nj * 16) == hipSuccess &&
                     hipMalloc((void **)&a->d_U, (size_t)128 * a->max_nj * 16) == hipSuccess &&
@@ -128,12 +146,25 @@ extern "C" int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx 
         sot_set_error("alsz: device allocation failed for %llu OT extensions per call", (unsigned long long)max_count);
         return SOT_ENOMEM;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_alsz_reg_mu);
+        g_alsz_reg.push_back(a);
+    }
     *out = a;
     return SOT_OK;
 }
 extern "C" void sot_alsz_ctx_destroy(sot_alsz_ctx *a) { alsz_free(a); }
-extern "C" void *sot_alsz_ctx_msgs_dev(sot_alsz_ctx *a) { return a ? a->d_out : nullptr; }
-extern "C" void *sot_alsz_ctx_u_dev(sot_alsz_ctx *a) { return a ? a->d_U : nullptr; }
+// the pointers are fixed at creation; the lock orders the read behind a call in flight on another thread
+extern "C" void *sot_alsz_ctx_msgs_dev(sot_alsz_ctx *a) {
+    if (!a) return nullptr;
+    std::lock_guard<std::mutex> lk(a->mu);
+    return a->d_out;
+}
+extern "C" void *sot_alsz_ctx_u_dev(sot_alsz_ctx *a) {
+    if (!a) return nullptr;
+    std::lock_guard<std::mutex> lk(a->mu);
+    return a->d_U;
+}
 extern "C" int sot_alsz_ctx_sync(sot_alsz_ctx *a) {
     if (!a) return SOT_EINVAL;
     std::lock_guard<std::mutex> lk(a->mu);
@@ -188,6 +219,7 @@ extern "C" int sot_alsz_ctx_receive(sot_alsz_ctx *a, const void *base_ots, const
     hipLaunchKernelGGL(k_alsz<false>, dim3(alsz_grid(nj)), dim3(AZ_THREADS), 0, a->stream, a->d_rks, a->d_ch,
                        make_uint4(0, 0, 0, 0), (const uint8_t *)nullptr, a->d_U, nj, count, a->d_out);
     SOT_HIP(hipGetLastError());
+    SOT_HIP(hipEventRecord(a->done, a->stream));
     a->last_count = count, a->last_nj = nj;
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, a->d_out, count * 16, hipMemcpyDeviceToHost, a->stream));
     // row r of the device matrix is nj Blocks wide, the caller's is count / 8 bytes
@@ -213,6 +245,14 @@ extern "C" int sot_alsz_ctx_send(sot_alsz_ctx *a, const void *base_ots, const vo
     for (int i = 0; i < 128; i++) bc[i] = (((const uint8_t *)base_choices)[i >> 3] >> (i & 7)) & 1;
     SOT_HIP(hipMemcpyAsync(a->d_bc, bc, 128, hipMemcpyHostToDevice, a->stream));
     const blk_t *U = (const blk_t *)u_dev;
+    if (!u_rows) {
+        // u_dev is the u-row matrix of a receiver context on this GPU (in-process two-party runs): its kernel runs on that
+        // context's stream, so this stream waits for the event recorded behind it. A pointer that belongs to no live
+        // context is the caller's own buffer and must be complete before the call (include/flute_sot.h).
+        std::lock_guard<std::mutex> rl(g_alsz_reg_mu);
+        for (sot_alsz_ctx *p : g_alsz_reg)
+            if (p != a && p->d_U == u_dev && p->device == a->device) SOT_HIP(hipStreamWaitEvent(a->stream, p->done, 0));
+    }
     if (u_rows) {
         if (cols % 16) SOT_HIP(hipMemsetAsync(a->d_U, 0, (size_t)128 * nj * 16, a->stream));  // rows end inside a Block
         SOT_HIP(hipMemcpy2DAsync(a->d_U, nj * 16, u_rows, cols, cols, 128, hipMemcpyHostToDevice, a->stream));
@@ -221,6 +261,7 @@ extern "C" int sot_alsz_ctx_send(sot_alsz_ctx *a, const void *base_ots, const vo
     hipLaunchKernelGGL(k_alsz<true>, dim3(alsz_grid(nj)), dim3(AZ_THREADS), 0, a->stream, a->d_rks, (const blk_t *)nullptr,
                        delta, a->d_bc, (blk_t *)U, nj, count, a->d_out);
     SOT_HIP(hipGetLastError());
+    SOT_HIP(hipEventRecord(a->done, a->stream));
     a->last_count = count, a->last_nj = nj;
     if (msgs_out) {
         SOT_HIP(hipMemcpyAsync(msgs_out, a->d_out, count * 32, hipMemcpyDeviceToHost, a->stream));
@@ -256,7 +297,8 @@ extern "C" int sot_alsz_send(int device, const void *base_ots, const void *base_
 
 // ------------------------------------------------------------------------------------------------
 // The one entry point that allocates nothing (no counterpart in the reference; for callers that cannot call hipMalloc:
-// code under HIP graph capture, tight serving loops, harnesses that forbid it). Same computation and same kernel as
+// tight serving loops, harnesses that forbid allocation). Synchronous on the null stream (blocking copies), so NOT usable
+// inside a HIP stream capture. Same computation and same kernel as
 // sot_alsz_receive, but every device buffer -- the 256 expanded base-OT keys, the padded choice blocks, the u-row
 // matrix and the hashed messages -- lives in ONE file-scope device array of a fixed, modest size, so the call makes no
 // hipMalloc / hipFree and no host heap allocation either. Each GPU holds its own copy of the array until the process

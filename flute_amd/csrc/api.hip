@@ -452,6 +452,37 @@ extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_
     return SOT_OK;
 }
 
+extern "C" int sot_blocks_to_device(sot_ctx *c, int what, const void *delta, void *dst_device, uint64_t dst_bytes) {
+    CHECK_CTX(c);
+    if (what < SOT_OUT_B || what > SOT_OUT_RECEIVER_MSGS) {
+        sot_set_error("blocks_to_device: unknown output %d", what);
+        return SOT_EINVAL;
+    }
+    const uint64_t bytes = c->n_out * (what == SOT_OUT_SENDER_MSGS ? 32 : 16);
+    if (!dst_device || dst_bytes < bytes) {
+        sot_set_error("blocks_to_device: destination of %llu bytes, need %llu", (unsigned long long)dst_bytes,
+                      (unsigned long long)bytes);
+        return SOT_EINVAL;
+    }
+    if (what == SOT_OUT_SENDER_MSGS) {
+        if (!delta) {
+            sot_set_error("blocks_to_device: the sender's hash needs delta");
+            return SOT_EINVAL;
+        }
+        return hash_sender(c, delta, nullptr, (blk_t *)dst_device);
+    }
+    if (what == SOT_OUT_RECEIVER_MSGS) return hash_receiver(c, nullptr, nullptr, (blk_t *)dst_device);
+    const int role = what == SOT_OUT_B ? SOT_ROLE_SENDER : SOT_ROLE_RECEIVER;
+    if (!c->role[role].encoded) {
+        sot_set_error("blocks_to_device before qc_encode");
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    SOT_HIP(hipMemcpyAsync(dst_device, c->role[role].enc, bytes, hipMemcpyDeviceToDevice, c->stream));
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    return SOT_OK;
+}
+
 extern "C" int sot_random_silent_send(sot_ctx *c, const void *base_ots, const void *delta, const void *seed,
                                       uint64_t num_threads, void *tg_sums_out, void *tg_last_out, void *msgs_out) {
     CHECK_CTX(c);

@@ -661,25 +661,28 @@ int ggm_upload_rT(sot_ctx *c, int role, const void *rT) {
     return SOT_OK;
 }
 
-int hash_sender(sot_ctx *c, const void *delta, void *msgs_out) {
+int hash_sender(sot_ctx *c, const void *delta, void *msgs_out, blk_t *dst_dev) {
     const sot_conf &cf = c->conf;
     if (!c->role[SOT_ROLE_SENDER].encoded) {
         sot_set_error("sender_hash before qc_encode");
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(c->device));
-    SOT_TRY(ensure_tmp(c, c->n_out * 32));
+    if (!dst_dev) {
+        SOT_TRY(ensure_tmp(c, c->n_out * 32));
+        dst_dev = (blk_t *)c->d_tmp;
+    }
     blk_t d;
     memcpy(&d, delta, 16);
     SOT_LAUNCH(c, KID_SENDER_HASH, k_sender_hash, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
-                       c->role[SOT_ROLE_SENDER].enc, d, c->n_out, (blk_t *)c->d_tmp);
+                       c->role[SOT_ROLE_SENDER].enc, d, c->n_out, dst_dev);
     SOT_HIP(hipGetLastError());
-    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, c->n_out * 32, hipMemcpyDeviceToHost, c->stream));
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, dst_dev, c->n_out * 32, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
 }
 
-int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
+int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out, blk_t *dst_dev) {
     const sot_conf &cf = c->conf;
     if (!c->role[SOT_ROLE_RECEIVER].encoded) {
         sot_set_error("receiver_hash before qc_encode");
@@ -690,12 +693,15 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out) {
         return SOT_ESTATE;
     }
     SOT_HIP(hipSetDevice(c->device));
-    SOT_TRY(ensure_tmp(c, c->n_out * 32));
+    if (!dst_dev) {
+        SOT_TRY(ensure_tmp(c, c->n_out * 32));
+        dst_dev = (blk_t *)c->d_tmp;
+    }
     uint64_t nw = (c->n_out + 63) / 64;
     SOT_LAUNCH(c, KID_RECEIVER_HASH, k_receiver_hash, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK),
-                       c->role[SOT_ROLE_RECEIVER].enc, c->n_out, (blk_t *)c->d_tmp, c->d_chw);
+                       c->role[SOT_ROLE_RECEIVER].enc, c->n_out, dst_dev, c->d_chw);
     SOT_HIP(hipGetLastError());
-    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, c->d_tmp, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
+    if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, dst_dev, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
     if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_chw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;

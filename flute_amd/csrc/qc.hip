@@ -130,22 +130,29 @@ __global__ void __launch_bounds__(256)
     k_sparse_choice(const uint32_t *__restrict__ a2, uint64_t P, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t n,
                     uint8_t *__restrict__ C) {
     __shared__ uint64_t sp[256];
-    for (uint32_t i = threadIdx.x; i < npts; i += blockDim.x) sp[i] = pts[i];
-    __syncthreads();
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t k0 = 32 * w;
-    if (k0 >= n) return;
     uint32_t v = 0;
-    for (uint32_t i = 0; i < npts; i++) {
-        const uint64_t e = sp[i];
-        if (e == SC_DROPPED) continue;
-        const uint64_t pos = e & ~(1ull << 63);
-        if (e >> 63) {
-            if ((pos >> 5) == w) v ^= 1u << (pos & 31);
-        } else {
-            v ^= cyc32(a2, P, k0 >= pos ? k0 - pos : k0 + P - pos);
-        }
+    // the points pass through LDS in chunks of 256 (`parts` is 120 or 128 for scaler 2 at 128-bit security, but any
+    // geometry sot_configure accepts works: quasi_cyclic_encode.rs:104-117 has no limit)
+    for (uint32_t c0 = 0; c0 < npts; c0 += 256) {
+        const uint32_t cn = npts - c0 < 256 ? npts - c0 : 256;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cn; i += blockDim.x) sp[i] = pts[c0 + i];
+        __syncthreads();
+        if (k0 < n)
+            for (uint32_t i = 0; i < cn; i++) {
+                const uint64_t e = sp[i];
+                if (e == SC_DROPPED) continue;
+                const uint64_t pos = e & ~(1ull << 63);
+                if (e >> 63) {
+                    if ((pos >> 5) == w) v ^= 1u << (pos & 31);
+                } else {
+                    v ^= cyc32(a2, P, k0 >= pos ? k0 - pos : k0 + P - pos);
+                }
+            }
     }
+    if (k0 >= n) return;
     if (k0 + 32 <= n) {
         uint32_t o[8];
 #pragma unroll
@@ -2862,8 +2869,8 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, in
     const uint32_t *sb = nullptr;
     if (role == SOT_ROLE_RECEIVER && !packed) {
         // the choice vector: sparse sum of shifts of a' (k_sparse_choice); A itself is the plain encode of all 128 rows
-        if (npoints > 256 || cf.n > c->tmp_bytes) {
-            sot_set_error("internal: unpacked choice vector does not fit (points %llu)", (unsigned long long)npoints);
+        if (cf.n > c->tmp_bytes) {  // cannot happen: the staging buffer holds n x 32 bytes
+            sot_set_error("internal: the staging buffer is smaller than the choice vector (%llu bytes)", (unsigned long long)cf.n);
             return SOT_EINVAL;
         }
         std::vector<uint64_t> e(npoints);

@@ -263,6 +263,7 @@ extern "C" int sot_ctx_create_sharded(uint64_t n, uint64_t scaler, int device, u
 
 extern "C" int sot_shard_info_get(const sot_ctx *c, sot_shard_info *o) {
     if (!c || !o) return SOT_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(const_cast<sot_ctx *>(c)->mu);
     const shard_state &s = c->sh;
     o->rank = s.rank, o->world = s.world;
     o->set0 = c->ggm_set0, o->nsets_local = c->ggm_nsets;
@@ -348,8 +349,10 @@ extern "C" int sot_shard_qc_encode(sot_ctx *c, const uint64_t *points, uint64_t 
         sot_set_error("sot_shard_qc_encode before the leaf slices are in place (sot_shard_unpack_leaves / _local_leaves)");
         return SOT_ESTATE;
     }
-    if (!points || npoints != c->conf.parts) {
-        sot_set_error("receiver encode needs the %llu noisy points", (unsigned long long)c->conf.parts);
+    // the receiver's noise indicator sb replaces its bit row 0, which lives on rank 0: only that rank reads the points
+    if (c->sh.rank == 0 && (!points || npoints != c->conf.parts)) {
+        sot_set_error("receiver encode needs the %llu noisy points (rank 0 holds the receiver's bit row 0)",
+                      (unsigned long long)c->conf.parts);
         return SOT_EINVAL;
     }
     SOT_HIP(hipSetDevice(c->device));

@@ -190,8 +190,9 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
                         const void *tg_last);
 int ggm_download_rT(sot_ctx *c, int role, void *out);
 int ggm_upload_rT(sot_ctx *c, int role, const void *rT);
-int hash_sender(sot_ctx *c, const void *delta, void *msgs_out);
-int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out);
+// dst_dev: where the hashed messages go on the device (nullptr = the context's staging buffer)
+int hash_sender(sot_ctx *c, const void *delta, void *msgs_out, blk_t *dst_dev = nullptr);
+int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out, blk_t *dst_dev = nullptr);
 int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64_t *cc);
 int hash_mt_role_bits(sot_ctx *c, int role, const void *delta, uint64_t *dst_device);
 int util_transpose128(int device, const void *in, void *out, uint64_t ntiles);

@@ -113,6 +113,35 @@ def gather_sharded_words(local, world):
     return flat.reshape(world, 3, -1).permute(1, 0, 2).reshape(3, -1)
 
 
+def gather_sharded_blocks(engine, what, world, delta=None, buf=None):
+    """The whole output vector of a sharded expansion on every rank (north_star: "RCCL all-gather over xGMI reassembles
+    the output vector"; the reference returns it whole: silent_ot/mod.rs:193-211, :391-404). `what`: engine.OUT_B /
+    OUT_A (n Blocks), OUT_SENDER_MSGS (n x [Block; 2]) or OUT_RECEIVER_MSGS (n Blocks). Each rank writes its n_local
+    outputs into a chunk-sized slot (sot_blocks_to_device; the last rank's slot is ragged), ONE all_gather_into_tensor
+    concatenates the slots in rank order, the first n entries are the vector. Returns (int64 tensor [n, 2] or [n, 2, 2]
+    viewing the gathered buffer, the reusable local buffer)."""
+    import torch
+    import torch.distributed as dist
+    per = 4 if what == engine.OUT_SENDER_MSGS else 2  # int64 words per output
+    chunk = engine.chunk if world > 1 else engine.n_out
+    n = engine.conf.n
+    if buf is None:
+        buf = torch.zeros(chunk * per, dtype=torch.int64, device=torch.device("cuda", engine.device))
+    engine.blocks_to_device(what, buf.data_ptr(), buf.numel() * 8, delta=delta)
+    if world <= 1:
+        flat = buf
+    else:
+        flat = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)
+        if dist.get_backend() == "gloo":  # rehearsals of GPU ranks over gloo: staged through the host
+            h = torch.empty(flat.numel(), dtype=buf.dtype)
+            dist.all_gather_into_tensor(h, buf.cpu())
+            flat.copy_(h)
+        else:
+            dist.all_gather_into_tensor(flat, buf)
+    out = flat[:n * per]
+    return (out.reshape(n, 2, 2) if per == 4 else out.reshape(n, 2)), buf
+
+
 class ShardedPipeline:
     """One rank's side of a sharded precompute_mts step (gmw/src/mul_triple/silent_ot.rs:79-114 for ONE expansion over
     `world` GPUs). `exchange(send, recv)` is the all-to-all: all_to_all_bytes over torch.distributed by default; the

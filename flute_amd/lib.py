@@ -32,7 +32,7 @@ EXPORTS = [
     "sot_last_error", "sot_device_count", "sot_configure", "sot_ctx_create", "sot_ctx_destroy", "sot_ctx_conf",
     "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
     "sot_sender_expand", "sot_receiver_expand", "sot_receiver_points", "sot_download_rT", "sot_qc_encode",
-    "sot_qc_encode2", "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_mt_role_bits_to_device", "sot_random_silent_send",
+    "sot_qc_encode2", "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_blocks_to_device", "sot_mt_role_bits_to_device", "sot_random_silent_send",
     "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
     "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
@@ -88,6 +88,7 @@ def load_library():
     L.sot_receiver_hash.argtypes = [P, P, P]
     L.sot_mt_bits.argtypes = [P, P, P, P, P]
     L.sot_mt_bits_to_device.argtypes = [P, P, u64]
+    L.sot_blocks_to_device.argtypes = [P, i32, P, P, u64]
     L.sot_random_silent_send.argtypes = [P, P, P, P, u64, P, P, P]
     L.sot_random_silent_receive.argtypes = [P, P, P, P, P, P, P]
     L.sot_prof_enable.argtypes = [P, i32]

@@ -273,6 +273,14 @@ class Engine:
         """3 * ceil(n / 64): length in u64 of the a | b | c buffer of mt_bits_to_device."""
         return 3 * ((self.n_out + 63) // 64)
 
+    OUT_B, OUT_A, OUT_SENDER_MSGS, OUT_RECEIVER_MSGS = 0, 1, 2, 3
+
+    def blocks_to_device(self, what, device_ptr, nbytes, delta=None):
+        """B / A / Sender::hash / Receiver::hash output of this context (this rank's n_out outputs when sharded) into a
+        caller-owned device buffer: sot_blocks_to_device"""
+        d = _blk(delta) if delta is not None else None
+        check(self.lib.sot_blocks_to_device(self.h, what, _p(d) if d is not None else None, C.c_void_p(device_ptr), nbytes))
+
     def mt_bits_to_device(self, device_ptr, nbytes):
         """a | b | c words of the last mt_bits() into a caller-owned device buffer (a torch tensor's data_ptr())."""
         check(self.lib.sot_mt_bits_to_device(self.h, C.c_void_p(device_ptr), nbytes))

@@ -140,6 +140,19 @@ int sot_mt_role_bits_to_device(sot_ctx *ctx, int role, const void *delta, void *
  * MulTriples live in host memory, gmw/src/mul_triple/mod.rs:30-35): this is what a multi-GPU party hands to the
  * RCCL all-gather that reassembles its MT store from the per-GPU instances. */
 int sot_mt_bits_to_device(sot_ctx *ctx, void *dst_device, uint64_t dst_bytes);
+/* The Block outputs of this context -- of this rank's n_local outputs on a sharded one -- written straight into a
+ * caller-owned DEVICE buffer on the context's GPU, synchronous on return. what = SOT_OUT_B: the sender's encoded vector B
+ * (correlated_silent_send, silent_ot/mod.rs:217), n_out Blocks; SOT_OUT_A: the receiver's A (:410); SOT_OUT_SENDER_MSGS:
+ * Sender::hash (:275-287), n_out x [Block; 2], needs delta; SOT_OUT_RECEIVER_MSGS: Receiver::hash (:470-482), n_out Blocks
+ * (the choice words stay in the context: sot_receiver_hash with msgs_out = NULL returns them). The reference returns these
+ * vectors whole in host memory (:193-211, :391-404); on a sharded context this is what the RCCL all-gather that
+ * reassembles them reads (flute_amd/dist.py::gather_sharded_blocks; north_star: "all-gather over xGMI reassembles the
+ * output vector"). */
+#define SOT_OUT_B 0
+#define SOT_OUT_A 1
+#define SOT_OUT_SENDER_MSGS 2
+#define SOT_OUT_RECEIVER_MSGS 3
+int sot_blocks_to_device(sot_ctx *ctx, int what, const void *delta, void *dst_device, uint64_t dst_bytes);
 
 /* ---- one expansion sharded over the GPUs of a node (no counterpart in the reference, whose parallelism is
  * rayon threads: tree groups pprf.rs:128, bit rows quasi_cyclic_encode.rs:35-46, column tiles :140-151) -------------
@@ -175,7 +188,9 @@ int sot_shard_unpack_leaves(sot_ctx *ctx, const void *recv_dev);
 /* ggm_replicated: cut this rank's rows out of the locally expanded leaves */
 int sot_shard_local_leaves(sot_ctx *ctx);
 /* dual_encode + dual_encode2(packed) of this rank's bit rows of both roles -> send_dev (device,
- * world * x2_bytes_per_peer): the send buffer of exchange #2; synchronous */
+ * world * x2_bytes_per_peer): the send buffer of exchange #2; synchronous. points / npoints (the `parts` noisy positions
+ * S of the receiver) are read on rank 0 only -- the noise vector replaces the receiver's bit row 0, which rank 0 owns --
+ * and may be NULL / 0 on the other ranks. */
 int sot_shard_qc_encode(sot_ctx *ctx, const uint64_t *points, uint64_t npoints, void *send_dev);
 /* recv_dev (device, world * x2_bytes_per_peer) -> this rank's n_local whole Blocks B and A */
 int sot_shard_unpack_encoded(sot_ctx *ctx, const void *recv_dev);
@@ -241,7 +256,13 @@ int sot_alsz_send(int device, const void *base_ots, const void *base_choices, co
 /* Device-resident OT-extension context: one zappot::ot_ext::Sender or Receiver instance (ot_ext/mod.rs:28-46, :144-154)
  * whose device buffers (expanded keys, choices, the 128 x count u-row matrix, the hashed messages) are allocated once,
  * for up to max_count extensions per call. The one-shot sot_alsz_receive / sot_alsz_send above are this context created
- * and destroyed around a single call. Calls on one context are serialised by a lock; they run on the context's stream. */
+ * and destroyed around a single call. Calls on one context are serialised by a lock; they run on the context's own
+ * (non-blocking) stream. ORDERING of device-resident hand-offs: sot_alsz_ctx_send given the sot_alsz_ctx_u_dev pointer
+ * of a live receiver context on the same GPU waits (stream-side, hipStreamWaitEvent) for that context's last call, so
+ * receive -> send needs no sync in between; any OTHER device pointer handed in (u_dev of the caller's own making,
+ * choice_bytes with choices_on_device) must be complete before the call, and before the pointers returned by
+ * sot_alsz_ctx_msgs_dev / sot_alsz_ctx_u_dev are read by anything else the producing context must be synced with
+ * sot_alsz_ctx_sync. */
 typedef struct sot_alsz_ctx sot_alsz_ctx;
 int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx **out);
 void sot_alsz_ctx_destroy(sot_alsz_ctx *actx);
@@ -261,7 +282,8 @@ void *sot_alsz_ctx_u_dev(sot_alsz_ctx *actx);
 int sot_alsz_ctx_sync(sot_alsz_ctx *actx);
 
 /* The one entry point that allocates nothing. NO counterpart in the reference: it exists for callers that cannot call
- * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same arguments,
+ * hipMalloc -- tight serving loops, harnesses that forbid allocation. It is synchronous on the null stream (blocking
+ * copies), so it is not for use inside a HIP stream capture. Same arguments,
  * computation and results as sot_alsz_receive, but the device buffers (expanded keys, padded choices, u-row matrix,
  * hashed messages) are one file-scope device array of 2 150 400 bytes per GPU, held until the process ends; the call
  * makes no hipMalloc / hipFree and no host heap allocation. count <= sot_alsz_noalloc_max_count() = 65 536 OTs per call,

@@ -64,7 +64,9 @@ def test_alsz_context_reused_across_calls_matches_oracle():
 
 def test_alsz_device_resident_handoff():
     """receiver results left in HBM, the sender reads the u rows device-to-device (in-process two-party run), and the
-    downloaded device buffers equal the host-buffer path"""
+    downloaded device buffers equal the host-buffer path. NO sync between the two calls on purpose: the contexts run on
+    two non-blocking streams, and sot_alsz_ctx_send orders itself behind the receiver context whose u_dev it is handed
+    (hipStreamWaitEvent on that context's `done` event, csrc/alsz.hip)"""
     import torch
     from flute_amd import ot_ext
     from oracle import alsz_oracle as az

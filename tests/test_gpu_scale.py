@@ -1,6 +1,7 @@
-"""Full-size GPU checks: n = 2^20 bit-exact against the oracle; n = 2^24 (BASELINE.json's size) through the
-size-independent properties of the reference's own tests (check_correlated / check_random, silent_ot/mod.rs:744-795;
-MT relation, gmw/src/mul_triple/silent_ot.rs:166-168)."""
+"""Full-size GPU checks, bit-exact against the oracle (products through the reference's bitpolymul2, oracle/_ref): n = 2^20,
+2^22, ragged sizes, the headline sizes 2^23 / 2^24 (both roles, packed AND unpacked choice bits, hashes, MT words) and
+2^25 / 2^26; n = 2^24 also through the size-independent properties of the reference's own tests (check_correlated /
+check_random, silent_ot/mod.rs:744-795; MT relation, gmw/src/mul_triple/silent_ot.rs:166-168)."""
 import numpy as np
 import pytest
 
@@ -139,9 +140,11 @@ def test_2pow22_encode_matches_oracle_with_reference_multiplier(orc):
         eng.close()
 
 
-def _encode_both_vs_oracle(orc, n, T, seed, receiver=True, hashes=False):
+def _encode_both_vs_oracle(orc, n, T, seed, receiver=True, hashes=False, unpacked=False):
     """Sender B, receiver A (and with `hashes` the receiver's choice words and the MT words a, b, c of the context's
-    two instances) against the oracle whose products come from the reference's bitpolymul2 when oracle/_ref exists."""
+    two instances; with `unpacked` also ChoiceBitPacking::False: all 128 rows of A and the choice vector C from
+    k_sparse_choice, quasi_cyclic_encode.rs:104-117) against the oracle whose products come from the reference's
+    bitpolymul2 when oracle/_ref exists."""
     import flute_amd as fa
     conf = orc.configure(n)
     rng = np.random.default_rng(seed)
@@ -161,6 +164,9 @@ def _encode_both_vs_oracle(orc, n, T, seed, receiver=True, hashes=False):
             if hashes:
                 _, ch = eng.receiver_hash(download=False)
                 a, b, c = eng.mt_bits(delta)
+            if unpacked:
+                C_u = eng.qc_encode2(pts, packed=False)
+                A_u = eng.download_encoded(1)
     finally:
         eng.close()
     orc.use_reference_multiplier(True)
@@ -173,6 +179,11 @@ def _encode_both_vs_oracle(orc, n, T, seed, receiver=True, hashes=False):
         if receiver:
             o_rT_r = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
             o_A, _ = orc.qc_dual_encode2(conf, o_rT_r, pts, packed=True)
+            if unpacked:
+                o_Au, o_Cu = orc.qc_dual_encode2(conf, o_rT_r, pts, packed=False)
+                assert np.array_equal(A_u, o_Au), "unpacked A"
+                assert np.array_equal(C_u, np.asarray(o_Cu, dtype=np.uint8).reshape(-1)[:n]), "unpacked choice vector C"
+                del o_Au, o_Cu
             del o_rT_r
             assert np.array_equal(A, o_A)
             if hashes:
@@ -194,10 +205,11 @@ def test_odd_sizes_match_oracle(orc, n, T):
 def test_headline_size_matches_oracle(orc, log2n):
     """n = 2^24 is the size bench.py times (transform size m = 25: k_fft_low<1,16> with nb = 9, k_top<.,9>) and n = 2^23
     is m = 24: both roles, the receiver's choice words and the MT words, bit for bit against the oracle (silent_ot/
-    mod.rs:410-482, pprf.rs:456-535)."""
+    mod.rs:410-482, pprf.rs:456-535). At 2^24 also the unpacked receiver mode (A with all 128 rows, C from k_sparse_choice
+    over the full length) against orc.qc_dual_encode2(packed=False)."""
     if orc.ref_lib() is None:
         pytest.skip("oracle/_ref absent")
-    _encode_both_vs_oracle(orc, 1 << log2n, 4, 1000 + log2n, receiver=True, hashes=True)
+    _encode_both_vs_oracle(orc, 1 << log2n, 4, 1000 + log2n, receiver=True, hashes=True, unpacked=log2n == 24)
 
 
 @pytest.mark.parametrize("log2n", [25, 26])

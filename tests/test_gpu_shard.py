@@ -99,7 +99,10 @@ CASES = [(1000, 2, 2, False), (1000, 2, 4, False), (1000, 2, 8, False), (1000, 1
          # the row-half / slice skipping of 4 and 8 ranks on every low-kernel template (m = 22 ... 24) and a ragged size
          (100003, 3, 8, True), (1 << 21, 4, 4, False), (1 << 22, 4, 8, False), (1 << 23, 4, 4, False),
          (3 * 2 ** 20 + 12345, 5, 8, False),
-         (1 << 24, 4, 4, False)]  # m = 25: the persistent low kernel (k_fft_low_p) on one row half (64 live rows)
+         (1 << 24, 4, 4, False),  # m = 25: the persistent low kernel (k_fft_low_p) on one row half (64 live rows)
+         # every BASELINE config-3 shape: 2^24 over 2 ranks (replicated GGM: what bench.py --ggm auto picks there) and over
+         # 8 ranks, 2^26 over 4 and 8 ranks (m = 27: 32-plane passes, k_conv_wholeunits on 64 / 32 live rows)
+         (1 << 24, 4, 2, True), (1 << 24, 4, 8, False), (1 << 26, 4, 4, False), (1 << 26, 4, 8, False)]
 
 
 @pytest.mark.parametrize("n,T,world,replicated", CASES)
@@ -156,7 +159,7 @@ def test_sharded_context_refuses_whole_matrix_stages(fa):
         fa.ShardedEngine(1000, 2, 2)
 
 
-@pytest.mark.parametrize("n,T", [(1000, 2), (100003, 3), (1 << 20, 4)])
+@pytest.mark.parametrize("n,T", [(1000, 2), (100003, 3), (1 << 20, 4), (1 << 24, 4)])
 def test_role_split_equals_one_gpu(fa, n, T):
     """two GPUs by direction (flute_amd/dist.py::RoleSplitPipeline, sot_mt_role_bits_to_device): the sender instance on
     one context, the receiver instance on another, joined from their bit vectors = the MT words of one context"""

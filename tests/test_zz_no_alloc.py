@@ -1,6 +1,7 @@
 """The one entry point that allocates nothing, sot_alsz_receive_noalloc (include/flute_sot.h): called through the C ABI
-and compared bit for bit with the existing sot_alsz_receive on the same inputs, on two calls in a row, the second with
-a smaller input (the shared scratch array still holds the first call's bytes). Collected last on purpose."""
+and compared bit for bit with the existing sot_alsz_receive on the same inputs AND with the CPU oracle
+(oracle/alsz_oracle.py), on two calls in a row, the second with a smaller input (the shared scratch array still holds the
+first call's bytes). Collected last on purpose."""
 import ctypes as C
 
 import numpy as np
@@ -22,6 +23,10 @@ def _both(L, base, choice, count):
     assert L.sot_alsz_receive_noalloc(0, _p(base), _p(choice), count, _p(u1), _p(m1)) == 0, L.sot_last_error()
     assert np.array_equal(u0, u1), "u rows differ at count=%d" % count
     assert np.array_equal(m0, m1), "messages differ at count=%d" % count
+    from oracle import alsz_oracle as az
+    ou, om = az.receive_random(base, choice.tobytes(), count)
+    assert np.array_equal(u1, ou), "u rows differ from the oracle at count=%d" % count
+    assert np.array_equal(m1, om), "messages differ from the oracle at count=%d" % count
     return m1
 
 
