@@ -117,6 +117,9 @@ def aes128_workloads(fa, n, ms_per_step, lut):
         "gmw_aes_instances_per_s_mt_supply": mts_per_s / fa.AES128_BRISTOL_AND_GATES,
         "flute_aes_instances_per_s_mt_supply": mts_per_s / fa.AES128_LUT_SETUP_MTS,
     }
+    if lut and lut.get("gmw_aes128") and lut["gmw_aes128"].get("value"):
+        # measured, not derived: the 60 AND layers of the Bristol circuit's profile on this GPU (both parties)
+        out["gmw_aes_instances_per_s_and_layers"] = lut["gmw_aes128"]["value"]
     if lut and lut.get("value"):
         # the AND layers themselves (both parties on this GPU): sbox8 instances/s measured above / 200
         out["flute_aes_instances_per_s_setup_layers"] = lut["value"] / fa.AES128_SBOXES
@@ -142,20 +145,65 @@ def lut_online_bench(fa, cs, lam, B, reps):
     m = x ^ lam[0].reshape(B, 8) ^ lam[1].reshape(B, 8)
     rows = tmpl.rows(m)
     o = [rng.integers(0, 2, (B, 8), dtype=np.uint8) for _ in range(2)]
+    # host-buffer form once (checks the result), then the device-resident form timed: masked inputs / output-lambda shares /
+    # delta shares stay in HBM, the template tables are cached in the circuit, both parties' calls are queued and waited
+    # for once (sot_lut_online_eval_dev)
+    d0 = fa.online_delta_shares(cs[0], tmpl, B, rows, o[0], 0)
+    d1 = fa.online_delta_shares(cs[1], tmpl, B, rows, o[1], 1)
+    ok = bool(np.array_equal(d0 ^ d1 ^ o[0] ^ o[1], tmpl.plain(x)))
+    import torch
+    t_rows = torch.from_numpy(rows.copy()).cuda()
+    t_o = [torch.from_numpy(v.copy()).cuda() for v in o]
+    t_d = [torch.zeros((B, tmpl.n_luts), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
     total = 0.0
     for rep in range(reps + 1):
         t0 = time.perf_counter()
-        d0 = fa.online_delta_shares(cs[0], tmpl, B, rows, o[0], 0)
-        d1 = fa.online_delta_shares(cs[1], tmpl, B, rows, o[1], 1)
+        fa.online_delta_shares_dev(cs[0], tmpl, B, t_rows.data_ptr(), t_o[0].data_ptr(), t_d[0].data_ptr(), 0)
+        fa.online_delta_shares_dev(cs[1], tmpl, B, t_rows.data_ptr(), t_o[1].data_ptr(), t_d[1].data_ptr(), 1)
+        cs[0].engine.sync(), cs[1].engine.sync()
         if rep:
             total += time.perf_counter() - t0
-    ok = bool(np.array_equal(d0 ^ d1 ^ o[0] ^ o[1], tmpl.plain(x)))
+    ok = ok and bool(np.array_equal(t_d[0].cpu().numpy(), d0) and np.array_equal(t_d[1].cpu().numpy(), d1))
     dt = total / reps
     return {"metric": "FLUTE online LUT evaluation, sbox8.lut instances/s (both parties' delta shares on one GPU)",
             "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "batch": B, "ms_per_batch": dt * 1e3,
             "outputs_equal_plaintext_sbox": ok,
-            "note": "wall time of the two calls incl. upload of the masked inputs / output-lambda shares and download of the "
-                    "delta shares (1 byte per gate and instance each way); the device buffers are kept in the circuit between calls"}
+            "note": "device-resident: masked inputs, output-lambda shares and delta shares in HBM (1 byte per gate and instance "
+                    "each), template tables cached in the circuit; both parties' calls queued, one wait"}
+
+
+def gmw_aes128_bench(fa, eng, eng1, delta, delta_peer, n, reps):
+    """BASELINE config 5: Boolean GMW on the Baseline AES-128 Bristol circuit's AND-layer profile (60 layers, 6 400 AND gates
+    per instance: tests/golden/aes128_bristol_and_layers.json, computed from Baseline/bristol/aes_128.bristol by
+    tools/bristol_and_layers.py; the wiring inside the profile is synthetic -- the netlist is not shipped), as many SIMD
+    instances as the step's triples pay for, both parties' 60 layers in one call, triples from the same device store."""
+    prof = json.load(open(os.path.join(ROOT, "tests", "golden", "aes128_bristol_and_layers.json")))["and_gates_per_layer"]
+    k = n // sum(prof)
+    rng = np.random.default_rng(55)
+    circ = fa.gmw_and_layers([c * k for c in prof], 256 * k, rng)
+    ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
+    cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((eng, eng1))]
+    total = 0.0
+    for rep in range(reps + 1):
+        eng.mt_bits(delta, download=False)
+        eng1.mt_bits(delta_peer, download=False)
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        eng.sync(), eng1.sync()
+        t0 = time.perf_counter()
+        cs[0].run_layers_with(cs[1])
+        if rep:
+            total += time.perf_counter() - t0
+    prod = cs[0].values() ^ cs[1].values()
+    ok = bool(np.array_equal(prod[circ.n_inputs:], prod[circ.x_src] & prod[circ.y_src]))
+    for c in cs:
+        c.close()
+    dt = total / reps
+    return {"metric": "Boolean GMW AND layers of Baseline/bristol/aes_128.bristol, AES-128 instances/s (both parties on one GPU)",
+            "value": k / dt, "unit": "AES-128 instances/s", "instances": k, "and_layers": len(prof), "and_gates_per_instance": sum(prof),
+            "ms_per_batch": dt * 1e3, "and_gates_per_s": k * sum(prof) / dt, "products_correct": ok,
+            "note": "AND-layer profile of the real circuit (180/20/40/140/100/160 per round x 10), synthetic wiring inside it"}
 
 
 def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, log2b, reps):
@@ -188,12 +236,7 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
                 c.set_inputs(i)
             eng.sync(), eng1.sync()
             t0 = time.perf_counter()
-            for layer in range(circ.n_layers):
-                cs[0].layer_msg(layer, download=False)
-                cs[1].layer_msg(layer, download=False)
-                cs[0].layer_eval_from(layer, cs[1])
-                cs[1].layer_eval_from(layer, cs[0])
-            eng.sync(), eng1.sync()
+            cs[0].run_layers_with(cs[1])  # all 7 layers of both parties: one fused launch per layer, one wait
             if rep:
                 total += time.perf_counter() - t0
         v0, v1 = cs[0].values(), cs[1].values()
@@ -207,14 +250,21 @@ def lut_setup_bench(fa, eng, x, y, tg_x, delta, delta_peer, seed_peer, threads, 
             online = {"value": None, "note": "failed: %r" % (e,)}
         for c in cs:
             c.close()
+        gmw = None
+        try:
+            gmw = gmw_aes128_bench(fa, eng, eng1, delta, delta_peer, n, reps)
+        except Exception as e:  # secondary figure
+            gmw = {"value": None, "note": "failed: %r" % (e,)}
         dt = total / reps
         return {"online": online,
                 "metric": "FLUTE LUT setup, sbox8.lut instances/s (both parties' AND layers on one GPU)",
                 "value": B / dt, "unit": "sbox8 instances/s", "lut_gates_per_s": 8 * B / dt, "and_gates_per_s": 247 * B / dt,
                 "batch": B, "ms_per_batch": dt * 1e3, "layers": int(circ.n_layers), "mts_consumed": int(circ.n_gates),
                 "subset_products_correct": ok, "host_circuit_build_s": t_build,
-                "note": "7 layers x (2 messages + 2 evaluations), every call synchronous; triples come from the device "
-                        "MT store of the expansion above; host-side circuit build (graph walk) not in the timed region"}
+                "gmw_aes128": gmw,
+                "note": "7 layers, both parties, ONE call (sot_and_circ_run_layers_peer: a fused launch per layer, one host "
+                        "synchronisation); triples come from the device MT store of the expansion above; host-side circuit "
+                        "build (graph walk) not in the timed region"}
     finally:
         eng1.close()
 

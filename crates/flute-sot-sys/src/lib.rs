@@ -109,8 +109,11 @@ extern "C" {
     pub fn sot_and_circ_layer_msg(circ: *mut SotAndCirc, layer: u32, d_out: *mut u8, e_out: *mut u8) -> c_int;
     pub fn sot_and_circ_layer_eval(circ: *mut SotAndCirc, layer: u32, party_id: u32, d_peer: *const u8, e_peer: *const u8) -> c_int;
     pub fn sot_and_circ_layer_eval_peer(circ: *mut SotAndCirc, layer: u32, party_id: u32, peer: *mut SotAndCirc) -> c_int;
+    pub fn sot_and_circ_layer_eval_msg(circ: *mut SotAndCirc, layer: u32, party_id: u32, d_peer: *const u8, e_peer: *const u8, d_next_out: *mut u8, e_next_out: *mut u8) -> c_int;
+    pub fn sot_and_circ_run_layers_peer(circ0: *mut SotAndCirc, circ1: *mut SotAndCirc, first: u32, last: u32) -> c_int;
     pub fn sot_and_circ_values(circ: *mut SotAndCirc, bits_out: *mut u8) -> c_int;
     pub fn sot_lut_online_eval(circ: *mut SotAndCirc, first_instance: u32, batch: u32, n_luts: u32, n_in: u32, arity: *const u32, tt: *const u32, lsrc: *const u32, tcount: *const u32, masked_in: *const u8, lam_out: *const u8, party_id: u32, delta_share_out: *mut u8) -> c_int;
+    pub fn sot_lut_online_eval_dev(circ: *mut SotAndCirc, first_instance: u32, batch: u32, n_luts: u32, n_in: u32, arity: *const u32, tt: *const u32, lsrc: *const u32, tcount: *const u32, masked_in_dev: *const c_void, lam_out_dev: *const c_void, party_id: u32, delta_share_dev: *mut c_void) -> c_int;
     pub fn sot_mt_remaining(ctx: *const SotCtx) -> u64;
     pub fn sot_alsz_receive(device: c_int, base_ots: *const c_void, choice_bytes: *const u8, count: u64, u_rows_out: *mut u8, msgs_out: *mut c_void) -> c_int;
     pub fn sot_alsz_send(device: c_int, base_ots: *const c_void, base_choices: *const c_void, u_rows: *const u8, count: u64, msgs_out: *mut c_void) -> c_int;

@@ -9,7 +9,7 @@ from .lib import SotError, load_library, device_count  # noqa: F401
 from .silent_ot import (QuasiCyclicConf, Engine, ShardedEngine, Sender, Receiver, MultType,  # noqa: F401
                         sample_base_choice_bits, fake_base)
 from .mul_triple import MulTriples, SilentMtProvider  # noqa: F401
-from .lut_eval import LutTemplate, online_delta_shares  # noqa: F401
+from .lut_eval import LutTemplate, online_delta_shares, online_delta_shares_dev  # noqa: F401
 from .aes_lut import Aes128Flute  # noqa: F401
 from .lut_setup import (SetupCircuit, build_setup_circuit, replicate_setup_circuit, AndCircuit,  # noqa: F401
                         aes128_lut_gate_parents, aes128_setup_circuit, gmw_and_layers, AES128_SBOXES,

@@ -40,6 +40,7 @@ struct sot_and_circ {
     uint64_t le_tab_bytes = 0;
     uint8_t *le_items = nullptr;  // masked_in | lam_out | out, le_cap bytes each
     uint64_t le_cap = 0;
+    std::vector<uint8_t> le_tab_host;  // what le_tab holds: an unchanged template is not uploaded again
 };
 
 __device__ __forceinline__ uint32_t bit_at(const uint64_t *__restrict__ w, uint64_t i) {
@@ -83,6 +84,38 @@ __global__ void __launch_bounds__(256)
         }
         const unsigned long long bz = __ballot(z);
         if ((threadIdx.x & 63) == 0) out[j >> 6] = bz;
+    }
+}
+
+// Both parties' compute_msg + evaluate_interactive of one layer in ONE launch, for in-process two-party runs (both circuits
+// on this GPU: tests, benchmarks; sot_and_circ_run_layers_peer). Per gate exactly what k_and_msg and k_and_eval compute
+// for party 0 (vals0, triples a0 | b0 | c0 from bit m0) and party 1; the messages are still written out (d0, e0, d1, e1).
+struct and_party {
+    const uint64_t *vals;
+    const uint32_t *xpos, *ypos;
+    const uint64_t *mta, *mtb, *mtc;
+    uint64_t mt0;
+    uint64_t *dout, *eout, *out;
+};
+__global__ void __launch_bounds__(256) k_and_layer2(and_party p0, and_party p1, uint32_t goff, uint32_t cnt) {
+    const uint32_t cnt_pad = (cnt + 63) & ~63u;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt_pad; j += gridDim.x * blockDim.x) {
+        uint32_t d0 = 0, e0 = 0, d1 = 0, e1 = 0, z0 = 0, z1 = 0;
+        if (j < cnt) {
+            const uint32_t a0 = bit_at(p0.mta, p0.mt0 + j), b0 = bit_at(p0.mtb, p0.mt0 + j), c0 = bit_at(p0.mtc, p0.mt0 + j);
+            const uint32_t a1 = bit_at(p1.mta, p1.mt0 + j), b1 = bit_at(p1.mtb, p1.mt0 + j), c1 = bit_at(p1.mtc, p1.mt0 + j);
+            d0 = bit_at(p0.vals, p0.xpos[goff + j]) ^ a0, e0 = bit_at(p0.vals, p0.ypos[goff + j]) ^ b0;
+            d1 = bit_at(p1.vals, p1.xpos[goff + j]) ^ a1, e1 = bit_at(p1.vals, p1.ypos[goff + j]) ^ b1;
+            const uint32_t d = d0 ^ d1, e = e0 ^ e1;
+            z0 = (d & b0) ^ (e & a0) ^ c0 ^ (d & e);
+            z1 = (d & b1) ^ (e & a1) ^ c1;
+        }
+        const unsigned long long bd0 = __ballot(d0), be0 = __ballot(e0), bd1 = __ballot(d1), be1 = __ballot(e1);
+        const unsigned long long bz0 = __ballot(z0), bz1 = __ballot(z1);
+        if ((threadIdx.x & 63) == 0) {
+            p0.dout[j >> 6] = bd0, p0.eout[j >> 6] = be0, p1.dout[j >> 6] = bd1, p1.eout[j >> 6] = be1;
+            p0.out[j >> 6] = bz0, p1.out[j >> 6] = bz1;
+        }
     }
 }
 
@@ -294,6 +327,107 @@ extern "C" int sot_and_circ_layer_eval_peer(sot_and_circ *q, uint32_t layer, uin
     return and_eval_launch(q, layer, party_id, q->d_peer, q->e_peer);
 }
 
+// evaluate `layer` with the peer's message, then compute the message of layer + 1 at once: ONE host round trip per
+// network round instead of two (the next message depends on nothing but this layer's outputs, executor.rs:139-163)
+extern "C" int sot_and_circ_layer_eval_msg(sot_and_circ *q, uint32_t layer, uint32_t party_id, const uint8_t *d_peer,
+                                           const uint8_t *e_peer, uint8_t *d_next_out, uint8_t *e_next_out) {
+    if (!q || layer >= q->n_layers || party_id > 1 || !d_peer || !e_peer) return SOT_EINVAL;
+    sot_ctx *c = q->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!q->msg_done[layer] || q->msg_layer != (int64_t)layer) {
+        sot_set_error("and_circ: layer_eval_msg(%u) without this layer's pending layer_msg", layer);
+        return SOT_ESTATE;
+    }
+    const bool more = layer + 1 < q->n_layers;
+    const uint32_t cnt1 = more ? q->count[layer + 1] : 0;
+    if (more && (!c->mt_valid || c->mt_rem < cnt1)) {
+        sot_set_error("and_circ: layer %u needs %u multiplication triples, the store holds %llu", layer + 1, cnt1,
+                      (unsigned long long)(c->mt_valid ? c->mt_rem : 0));
+        return SOT_ESTATE;
+    }
+    SOT_HIP(hipSetDevice(c->device));
+    const uint64_t nw = (c->n_out + 63) / 64;
+    const uint64_t nb = ((uint64_t)q->count[layer] + 7) / 8;
+    SOT_HIP(hipMemsetAsync(q->d_peer, 0, q->msg_words * 8, c->stream));
+    SOT_HIP(hipMemsetAsync(q->e_peer, 0, q->msg_words * 8, c->stream));
+    SOT_HIP(hipMemcpyAsync(q->d_peer, d_peer, nb, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipMemcpyAsync(q->e_peer, e_peer, nb, hipMemcpyHostToDevice, c->stream));
+    SOT_LAUNCH(c, KID_AND_EVAL, k_and_eval, dim3(lgrid(q->count[layer])), dim3(256), q->d_own, q->e_own, q->d_peer, q->e_peer,
+               c->d_mt, c->d_mt + nw, c->d_mt + 2 * nw, q->mt0[layer], q->count[layer], party_id, q->vals + q->base[layer] / 64);
+    uint64_t mt0 = 0;
+    if (more) {  // stream order: the evaluation above has written this layer's outputs before the message kernel reads them
+        mt0 = c->mt_rem - cnt1;
+        SOT_LAUNCH(c, KID_AND_MSG, k_and_msg, dim3(lgrid(cnt1)), dim3(256), q->vals, q->xpos, q->ypos, q->goff[layer + 1], cnt1,
+                   c->d_mt, c->d_mt + nw, mt0, q->d_own, q->e_own);
+        const uint64_t nb1 = ((uint64_t)cnt1 + 7) / 8;
+        if (d_next_out) SOT_HIP(hipMemcpyAsync(d_next_out, q->d_own, nb1, hipMemcpyDeviceToHost, c->stream));
+        if (e_next_out) SOT_HIP(hipMemcpyAsync(e_next_out, q->e_own, nb1, hipMemcpyDeviceToHost, c->stream));
+    }
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c->stream));
+    q->msg_done[layer] = 0, q->evaluated[layer] = 1, q->msg_layer = -1;
+    if (more) {
+        c->mt_rem = mt0;
+        q->mt0[layer + 1] = mt0, q->msg_done[layer + 1] = 1, q->msg_layer = layer + 1, q->buf_layer = layer + 1;
+    }
+    return SOT_OK;
+}
+
+// Both parties' layers first .. last in one call for in-process two-party runs (circ0 = party 0, circ1 = party 1, both
+// on the same GPU; the reference's analogue is two executors over mpc_channel::in_memory): one fused launch per layer,
+// queued on party 0's stream, ONE host synchronisation at the end. Each party's triples come from the end of its own
+// context's store, exactly as layer_msg takes them.
+extern "C" int sot_and_circ_run_layers_peer(sot_and_circ *q0, sot_and_circ *q1, uint32_t first, uint32_t last) {
+    if (!q0 || !q1 || q0 == q1 || first > last || last >= q0->n_layers || q0->n_layers != q1->n_layers ||
+        q0->n_gates != q1->n_gates || q0->n_inputs != q1->n_inputs || q0->ctx->device != q1->ctx->device ||
+        q0->ctx == q1->ctx) {
+        sot_set_error("and_circ: run_layers_peer needs two circuits of the same shape on two contexts of one GPU and first <= last < n_layers");
+        return SOT_EINVAL;
+    }
+    for (uint32_t l = first; l <= last; l++)
+        if (q0->count[l] != q1->count[l]) return SOT_EINVAL;
+    sot_ctx *c0 = q0->ctx, *c1 = q1->ctx;
+    sot_ctx *ca = c0 < c1 ? c0 : c1, *cb = c0 < c1 ? c1 : c0;
+    std::lock_guard<std::recursive_mutex> lk1(ca->mu);
+    std::lock_guard<std::recursive_mutex> lk2(cb->mu);
+    uint64_t need = 0;
+    for (uint32_t l = first; l <= last; l++) need += q0->count[l];
+    for (sot_and_circ *q : {q0, q1}) {
+        if (q->msg_layer >= 0 || q->evaluated[first] || (first > 0 && !q->evaluated[first - 1])) {
+            sot_set_error("and_circ: run_layers_peer(%u..%u) out of order (a message is pending, or the layers before are "
+                          "not evaluated, or layer %u already is)", first, last, first);
+            return SOT_ESTATE;
+        }
+        if (!q->ctx->mt_valid || q->ctx->mt_rem < need) {
+            sot_set_error("and_circ: layers %u..%u need %llu multiplication triples, the store holds %llu", first, last,
+                          (unsigned long long)need, (unsigned long long)(q->ctx->mt_valid ? q->ctx->mt_rem : 0));
+            return SOT_ESTATE;
+        }
+    }
+    SOT_HIP(hipSetDevice(c0->device));
+    if (c1 != c0) SOT_HIP(hipStreamSynchronize(c1->stream));  // party 1's store and values are complete (normally idle already)
+    const uint64_t nw0 = (c0->n_out + 63) / 64, nw1 = (c1->n_out + 63) / 64;
+    uint64_t rem0 = c0->mt_rem, rem1 = c1->mt_rem;
+    for (uint32_t l = first; l <= last; l++) {
+        const uint32_t cnt = q0->count[l];
+        rem0 -= cnt, rem1 -= cnt;
+        and_party p0 = {q0->vals, q0->xpos, q0->ypos, c0->d_mt, c0->d_mt + nw0, c0->d_mt + 2 * nw0, rem0,
+                        q0->d_own, q0->e_own, q0->vals + q0->base[l] / 64};
+        and_party p1 = {q1->vals, q1->xpos, q1->ypos, c1->d_mt, c1->d_mt + nw1, c1->d_mt + 2 * nw1, rem1,
+                        q1->d_own, q1->e_own, q1->vals + q1->base[l] / 64};
+        SOT_LAUNCH(c0, KID_AND_EVAL, k_and_layer2, dim3(lgrid(cnt)), dim3(256), p0, p1, q0->goff[l], cnt);
+        q0->mt0[l] = rem0, q1->mt0[l] = rem1;
+    }
+    SOT_HIP(hipGetLastError());
+    SOT_HIP(hipStreamSynchronize(c0->stream));
+    c0->mt_rem = rem0, c1->mt_rem = rem1;
+    for (sot_and_circ *q : {q0, q1}) {
+        for (uint32_t l = first; l <= last; l++) q->msg_done[l] = 0, q->evaluated[l] = 1;
+        q->msg_layer = -1, q->buf_layer = last;
+    }
+    return SOT_OK;
+}
+
 extern "C" int sot_and_circ_values(sot_and_circ *q, uint8_t *bits_out) {
     if (!q || !bits_out) return SOT_EINVAL;
     sot_ctx *c = q->ctx;
@@ -400,11 +534,10 @@ static int le_reserve(void **buf, uint64_t *cap, uint64_t bytes) {
     return SOT_OK;
 }
 
-extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
-                                   const uint32_t *arity,
-                                   const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
-                                   const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id,
-                                   uint8_t *delta_share_out) {
+static int lut_online(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                      const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                      const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id, uint8_t *delta_share_out,
+                      bool on_device) {
     if (!q || !batch || !n_luts || !arity || !tt || !lsrc || (!tcount && q->n_layers) || !masked_in || !lam_out ||
         party_id > 1 || !delta_share_out)
         return SOT_EINVAL;
@@ -448,32 +581,67 @@ extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uin
     const uint64_t o_tc = o_ls + (uint64_t)n_luts * 1024, o_lb = o_tc + (((uint64_t)q->n_layers * 4 + 7) & ~7ull);
     const uint64_t tab_bytes = o_lb + (uint64_t)q->n_layers * 8 + 8;
     SOT_TRY(le_reserve(&q->le_tab, &q->le_tab_bytes, tab_bytes));
-    if (q->le_cap < items) {  // three byte arrays of le_cap entries each
-        uint64_t got = 0;
-        void *p = q->le_items;
-        q->le_items = nullptr, q->le_cap = 0;
-        SOT_TRY(le_reserve(&p, &got, 3 * items));
-        q->le_items = (uint8_t *)p, q->le_cap = items;
+    {
+        // one host image of the tables; uploaded only when it differs from what the device copy holds (a deeper circuit
+        // calls once per LUT layer with the same template: no PCIe traffic but the per-item arrays)
+        std::vector<uint8_t> img(tab_bytes, 0);
+        memcpy(img.data() + o_ar, arity, (uint64_t)n_luts * 4);
+        memcpy(img.data() + o_tt, tt, (uint64_t)n_luts * 32);
+        memcpy(img.data() + o_ls, lsrc, (uint64_t)n_luts * 1024);
+        if (q->n_layers) {
+            memcpy(img.data() + o_tc, tcount, (uint64_t)q->n_layers * 4);
+            memcpy(img.data() + o_lb, q->base.data(), (uint64_t)q->n_layers * 8);
+        }
+        if (img != q->le_tab_host) {
+            SOT_HIP(hipStreamSynchronize(c->stream));  // a kernel of the previous call may still read the old tables
+            SOT_HIP(hipMemcpy(q->le_tab, img.data(), tab_bytes, hipMemcpyHostToDevice));
+            q->le_tab_host.swap(img);
+        }
     }
     char *tb = (char *)q->le_tab;
-    uint32_t *d_ar = (uint32_t *)(tb + o_ar), *d_tt = (uint32_t *)(tb + o_tt), *d_ls = (uint32_t *)(tb + o_ls);
-    uint32_t *d_tc = (uint32_t *)(tb + o_tc);
-    uint64_t *d_lb = (uint64_t *)(tb + o_lb);
-    uint8_t *d_m = q->le_items, *d_lo = q->le_items + q->le_cap, *d_out = q->le_items + 2 * q->le_cap;
-    SOT_HIP(hipMemcpyAsync(d_ar, arity, (uint64_t)n_luts * 4, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(d_tt, tt, (uint64_t)n_luts * 32, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(d_ls, lsrc, (uint64_t)n_luts * 1024, hipMemcpyHostToDevice, c->stream));
-    if (q->n_layers) {
-        SOT_HIP(hipMemcpyAsync(d_tc, tcount, (uint64_t)q->n_layers * 4, hipMemcpyHostToDevice, c->stream));
-        SOT_HIP(hipMemcpyAsync(d_lb, q->base.data(), (uint64_t)q->n_layers * 8, hipMemcpyHostToDevice, c->stream));
+    const uint32_t *d_ar = (const uint32_t *)(tb + o_ar), *d_tt = (const uint32_t *)(tb + o_tt), *d_ls = (const uint32_t *)(tb + o_ls);
+    const uint32_t *d_tc = (const uint32_t *)(tb + o_tc);
+    const uint64_t *d_lb = (const uint64_t *)(tb + o_lb);
+    const uint8_t *d_m = masked_in, *d_lo = lam_out;
+    uint8_t *d_out = delta_share_out;
+    if (!on_device) {
+        if (q->le_cap < items) {  // three byte arrays of le_cap entries each
+            uint64_t got = 0;
+            void *p = q->le_items;
+            q->le_items = nullptr, q->le_cap = 0;
+            SOT_HIP(hipStreamSynchronize(c->stream));
+            SOT_TRY(le_reserve(&p, &got, 3 * items));
+            q->le_items = (uint8_t *)p, q->le_cap = items;
+        }
+        SOT_HIP(hipMemcpyAsync(q->le_items, masked_in, items, hipMemcpyHostToDevice, c->stream));
+        SOT_HIP(hipMemcpyAsync(q->le_items + q->le_cap, lam_out, items, hipMemcpyHostToDevice, c->stream));
+        d_m = q->le_items, d_lo = q->le_items + q->le_cap, d_out = q->le_items + 2 * q->le_cap;
     }
-    SOT_HIP(hipMemcpyAsync(d_m, masked_in, items, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(d_lo, lam_out, items, hipMemcpyHostToDevice, c->stream));
     const uint64_t grid = (items + 255) / 256;
     hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, first_instance, batch, n_luts, n_in, d_ar, d_tt,
                        d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipMemcpyAsync(delta_share_out, d_out, items, hipMemcpyDeviceToHost, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    if (!on_device) {
+        SOT_HIP(hipMemcpyAsync(delta_share_out, d_out, items, hipMemcpyDeviceToHost, c->stream));
+        SOT_HIP(hipStreamSynchronize(c->stream));
+    }
     return SOT_OK;
+}
+
+extern "C" int sot_lut_online_eval(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                                   const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                                   const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id,
+                                   uint8_t *delta_share_out) {
+    return lut_online(q, first_instance, batch, n_luts, n_in, arity, tt, lsrc, tcount, masked_in, lam_out, party_id,
+                      delta_share_out, false);
+}
+// the same with the per-item arrays (masked_in, lam_out, delta_share_out: batch x n_luts bytes each) in DEVICE memory on
+// the circuit's GPU: nothing crosses PCIe but the template tables the first time; queued on the context's stream and NOT
+// waited for (sot_ctx_sync; the arrays must be complete when the call is made and stay valid until then)
+extern "C" int sot_lut_online_eval_dev(sot_and_circ *q, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                                       const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                                       const void *masked_in_dev, const void *lam_out_dev, uint32_t party_id,
+                                       void *delta_share_dev) {
+    return lut_online(q, first_instance, batch, n_luts, n_in, arity, tt, lsrc, tcount, (const uint8_t *)masked_in_dev,
+                      (const uint8_t *)lam_out_dev, party_id, (uint8_t *)delta_share_dev, true);
 }

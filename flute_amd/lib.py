@@ -37,7 +37,8 @@ EXPORTS = [
     "sot_prof_read", "sot_transpose128", "sot_aes128_encrypt", "sot_cr_hash", "sot_qc_dual_encode_host",
     "sot_qc_transform_row", "sot_qc_log2_capacity", "sot_and_circ_create", "sot_and_circ_destroy",
     "sot_and_circ_set_inputs", "sot_and_circ_layer_msg", "sot_and_circ_layer_eval", "sot_and_circ_layer_eval_peer",
-    "sot_and_circ_values", "sot_lut_online_eval", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
+    "sot_and_circ_layer_eval_msg", "sot_and_circ_run_layers_peer",
+    "sot_and_circ_values", "sot_lut_online_eval", "sot_lut_online_eval_dev", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
     "sot_alsz_noalloc_max_count", "sot_alsz_ctx_create", "sot_alsz_ctx_destroy", "sot_alsz_ctx_receive",
     "sot_alsz_ctx_send", "sot_alsz_ctx_msgs_dev", "sot_alsz_ctx_u_dev", "sot_alsz_ctx_sync", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves",
     "sot_shard_unpack_leaves", "sot_shard_local_leaves", "sot_shard_qc_encode", "sot_shard_unpack_encoded",
@@ -112,6 +113,9 @@ def load_library():
     L.sot_and_circ_layer_msg.argtypes = [P, u32, P, P]
     L.sot_and_circ_layer_eval.argtypes = [P, u32, u32, P, P]
     L.sot_and_circ_layer_eval_peer.argtypes = [P, u32, u32, P]
+    L.sot_and_circ_layer_eval_msg.argtypes = [P, u32, u32, P, P, P, P]
+    L.sot_and_circ_run_layers_peer.argtypes = [P, P, u32, u32]
+    L.sot_lut_online_eval_dev.argtypes = [P, u32, u32, u32, u32, P, P, P, P, P, P, u32, P]
     L.sot_and_circ_values.argtypes = [P, P]
     L.sot_lut_online_eval.argtypes = [P, u32, u32, u32, u32, P, P, P, P, P, P, u32, P]
     L.sot_mt_role_bits_to_device.argtypes = [P, i32, P, P, u64]

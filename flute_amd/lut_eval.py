@@ -100,3 +100,14 @@ def online_delta_shares(and_circuit, template, batch, masked_rows, lam_out, part
     check(and_circuit.engine.lib.sot_lut_online_eval(and_circuit.h, first_instance, batch, t.n_luts, t.setup.n_inputs, p(t.arity), p(t.tt),
                                                      p(t.lsrc), p(t.tcount), p(m), p(lo), party_id, p(out)))
     return out
+
+
+def online_delta_shares_dev(and_circuit, template, batch, masked_rows_dev, lam_out_dev, out_dev, party_id, first_instance=0):
+    """online_delta_shares with the per-item arrays as DEVICE pointers (batch x n_luts bytes each, e.g. torch uint8 tensors'
+    data_ptr()) on the circuit's GPU: sot_lut_online_eval_dev. Queued on the engine's stream, not waited for
+    (and_circuit.engine.sync())."""
+    t = template
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    check(and_circuit.engine.lib.sot_lut_online_eval_dev(and_circuit.h, first_instance, batch, t.n_luts, t.setup.n_inputs,
+                                                         p(t.arity), p(t.tt), p(t.lsrc), p(t.tcount), C.c_void_p(masked_rows_dev),
+                                                         C.c_void_p(lam_out_dev), party_id, C.c_void_p(out_dev)))

@@ -223,6 +223,29 @@ class AndCircuit:
         """same, the peer's message taken device-to-device from another AndCircuit on the same GPU (benchmarks)"""
         check(self.engine.lib.sot_and_circ_layer_eval_peer(self.h, layer, self.party_id, peer.h))
 
+    def layer_eval_msg(self, layer, peer_d, peer_e, download=True):
+        """evaluate_interactive of `layer` + compute_msg of layer + 1 in one call (sot_and_circ_layer_eval_msg); returns the
+        next layer's (d, e), or None after the last layer"""
+        pd = np.ascontiguousarray(peer_d, dtype=np.uint8)
+        pe = np.ascontiguousarray(peer_e, dtype=np.uint8)
+        more = layer + 1 < self.circ.n_layers
+        if more and download:
+            nb = (int(self.circ.layer_counts[layer + 1]) + 7) // 8
+            d, e = np.zeros(nb, dtype=np.uint8), np.zeros(nb, dtype=np.uint8)
+            dp, ep = d.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p)
+        else:
+            d = e = dp = ep = None
+        check(self.engine.lib.sot_and_circ_layer_eval_msg(self.h, layer, self.party_id, pd.ctypes.data_as(C.c_void_p),
+                                                          pe.ctypes.data_as(C.c_void_p), dp, ep))
+        return (d, e) if more and download else None
+
+    def run_layers_with(self, peer, first=0, last=None):
+        """both parties' layers first .. last in one call (self = party 0, peer = party 1, same GPU):
+        sot_and_circ_run_layers_peer -- one fused launch per layer, one synchronisation"""
+        assert self.party_id == 0 and peer.party_id == 1
+        last = self.circ.n_layers - 1 if last is None else last
+        check(self.engine.lib.sot_and_circ_run_layers_peer(self.h, peer.h, first, last))
+
     def values(self):
         """all value bits (inputs, then AND outputs) in CREATION order, one 0/1 per value"""
         n = self.circ.n_inputs + self.circ.n_gates

@@ -219,6 +219,16 @@ int sot_and_circ_layer_eval(sot_and_circ *circ, uint32_t layer, uint32_t party_i
 /* same, the peer's message read device-to-device from the peer's circuit on the SAME GPU (in-process two-party
  * runs: tests, benchmarks; the reference's analogue is mpc_channel::in_memory) */
 int sot_and_circ_layer_eval_peer(sot_and_circ *circ, uint32_t layer, uint32_t party_id, sot_and_circ *peer);
+/* evaluate_interactive of `layer` with the peer's message AND compute_msg of layer + 1 in the same call: one host round
+ * trip per network round instead of two (the next layer's message depends only on this layer's outputs, executor.rs:139-163).
+ * d_next_out / e_next_out: the message of layer + 1 (ignored for the last layer; NULL leaves it on the device). */
+int sot_and_circ_layer_eval_msg(sot_and_circ *circ, uint32_t layer, uint32_t party_id, const uint8_t *d_peer,
+                                const uint8_t *e_peer, uint8_t *d_next_out, uint8_t *e_next_out);
+/* In-process two-party runs (tests, benchmarks; the reference's analogue is two Executors over mpc_channel::in_memory,
+ * executor.rs:74-193): layers first .. last of BOTH parties -- circ0 = party 0, circ1 = party 1, same circuit shape, two
+ * contexts on the same GPU -- in one call: one fused launch per layer (both parties' compute_msg + evaluate_interactive),
+ * one host synchronisation at the end. Each party's triples come from the end of its own context's store. */
+int sot_and_circ_run_layers_peer(sot_and_circ *circ0, sot_and_circ *circ1, uint32_t first, uint32_t last);
 /* gate_outputs()[0] of the executor (aby2_lut.rs:761): one byte 0/1 per value, inputs then gates in execution order */
 int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
 /* FLUTE ONLINE LUT evaluation: LutGate::compute_delta_share (aby2_lut.rs:209-277, expand :947-964) for
@@ -238,6 +248,12 @@ int sot_and_circ_values(sot_and_circ *circ, uint8_t *bits_out);
 int sot_lut_online_eval(sot_and_circ *circ, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
                         const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
                         const uint8_t *masked_in, const uint8_t *lam_out, uint32_t party_id, uint8_t *delta_share_out);
+/* sot_lut_online_eval with masked_in, lam_out and delta_share_out (batch x n_luts bytes each) in DEVICE memory on the
+ * circuit's GPU; the template tables are uploaded only when they differ from the previous call's. Queued on the context's
+ * stream and not waited for: sot_ctx_sync before the result is read. */
+int sot_lut_online_eval_dev(sot_and_circ *circ, uint32_t first_instance, uint32_t batch, uint32_t n_luts, uint32_t n_in,
+                            const uint32_t *arity, const uint32_t *tt, const uint32_t *lsrc, const uint32_t *tcount,
+                            const void *masked_in_dev, const void *lam_out_dev, uint32_t party_id, void *delta_share_dev);
 /* triples left in the context's store (MulTriples::len after the split_off_last calls so far) */
 uint64_t sot_mt_remaining(const sot_ctx *ctx);
 

@@ -61,6 +61,15 @@ def _check(fa, tmpl, batch, n, seed, oracle_instances):
         d1 = fa.online_delta_shares(c1, tmpl, batch, rows, o1, 1)
         # the protocol: Delta_out ^ lambda_out = the LUT's value on the plaintext inputs, every instance and gate
         assert np.array_equal(d0 ^ d1 ^ o0 ^ o1, tmpl.plain(x))
+        # the device-resident form (sot_lut_online_eval_dev: per-item arrays in HBM, tables cached, no wait): same bits
+        import torch
+        t_rows, t_o0 = torch.from_numpy(rows.copy()).cuda(), torch.from_numpy(o0.copy()).cuda()
+        t_out = torch.full((batch, tmpl.n_luts), 7, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        fa.online_delta_shares_dev(c0, tmpl, batch, t_rows.data_ptr(), t_o0.data_ptr(), t_out.data_ptr(), 0)
+        fa.online_delta_shares_dev(c0, tmpl, batch, t_rows.data_ptr(), t_o0.data_ptr(), t_out.data_ptr(), 0)  # cached tables
+        e0.sync()
+        assert np.array_equal(t_out.cpu().numpy(), d0)
         # each party's share against the restated compute_delta_share, fed with the SAME setup shares
         # setup() sorts a gate's input shares before taking the powerset (aby2_lut.rs:735), compute_delta_share walks the
         # powerset of the inputs in GATE order: the two orders agree when a gate lists its wires in ascending setup-input

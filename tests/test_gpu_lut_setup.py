@@ -222,19 +222,30 @@ def test_aes128_lut_setup_config4(fa):
         e1.close()
 
 
+def _aes128_and_layer_profile():
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aes128_bristol_and_layers.json")))
+    return d["and_gates_per_layer"]
+
+
 def test_aes128_bristol_and_layers_config5(fa):
-    """BASELINE config 5: multiplication triples for the Baseline AES-128 Bristol circuit (6 400 AND gates per instance,
-    Baseline/bristol/aes_128.bristol) from the SAME device store the FLUTE LUT path draws on: k instances' AND gates
-    run as Boolean GMW layers (synthetic wiring with the circuit's AND count: the netlist is not shipped), the
-    reconstructed outputs are the ANDs of the reconstructed inputs and the store shrinks by 6 400 per instance --
-    7.7 times fewer triples per AES than the LUT path's 49 400."""
+    """BASELINE config 5: multiplication triples for the Baseline AES-128 Bristol circuit from the SAME device store the
+    FLUTE LUT path draws on. The AND-layer profile is the real circuit's (tests/golden/aes128_bristol_and_layers.json,
+    computed from Baseline/bristol/aes_128.bristol by tools/bristol_and_layers.py: 6 400 AND gates in 60 layers of
+    180 / 20 / 40 / 140 / 100 / 160 per round; numbers only, the netlist is not shipped, so the wiring inside the
+    profile is synthetic): k instances run as Boolean GMW layers, once layer by layer and once through
+    sot_and_circ_run_layers_peer; the reconstructed outputs are the ANDs of the reconstructed inputs and the store
+    shrinks by 6 400 per instance -- 7.7 times fewer triples per AES than the LUT path's 49 400."""
+    prof = _aes128_and_layer_profile()
+    assert sum(prof) == 6400 == fa.AES128_BRISTOL_AND_GATES and len(prof) == 60
     n = 1 << 16
     e0, e1, _ = _two_providers(fa, n, 2, 45)
     try:
         k = 5
         rng = np.random.default_rng(5)
-        circ = fa.gmw_and_layers([fa.AES128_BRISTOL_AND_GATES * k // 40] * 40, 256 * k, rng)
-        assert circ.n_gates == 6400 * k
+        circ = fa.gmw_and_layers([c * k for c in prof], 256 * k, rng)
+        assert circ.n_gates == 6400 * k and circ.n_layers == 60
         ins = [rng.integers(0, 2, circ.n_inputs, dtype=np.uint8) for _ in range(2)]
         cs = [fa.AndCircuit(e, circ, p) for p, e in enumerate((e0, e1))]
         for c, i in zip(cs, ins):
@@ -244,10 +255,78 @@ def test_aes128_bristol_and_layers_config5(fa):
             cs[1].layer_msg(layer, download=False)
             cs[0].layer_eval_from(layer, cs[1])
             cs[1].layer_eval_from(layer, cs[0])
-        prod = cs[0].values() ^ cs[1].values()
+        v = [c.values() for c in cs]
+        prod = v[0] ^ v[1]
         assert np.array_equal(prod[circ.n_inputs:], prod[circ.x_src] & prod[circ.y_src])
         assert e0.lib.sot_mt_remaining(e0.h) == n - 6400 * k
         assert n // fa.AES128_BRISTOL_AND_GATES == 10 and n // fa.AES128_LUT_SETUP_MTS == 1
+        # the same 60 layers in ONE call: the next 6400 k triples of each store, so other share values, the same products
+        for c, i in zip(cs, ins):
+            c.set_inputs(i)
+        cs[0].run_layers_with(cs[1])
+        w = [c.values() for c in cs]
+        prod2 = w[0] ^ w[1]
+        assert np.array_equal(prod2, prod)
+        assert e0.lib.sot_mt_remaining(e0.h) == n - 2 * 6400 * k == e1.lib.sot_mt_remaining(e1.h)
+    finally:
+        e0.close()
+        e1.close()
+
+
+def test_run_layers_peer_and_eval_msg_equal_the_layerwise_path(fa):
+    """sot_and_circ_run_layers_peer (one fused launch per layer for both parties) and sot_and_circ_layer_eval_msg (evaluate +
+    next message in one call) against the oracle's two-party run: same messages, same value bits, same triple consumption
+    as layer_msg / layer_eval."""
+    from oracle import lut_setup_oracle as lo
+    from flute_amd.lib import SotError
+    luts = [tuple(l) for l in CIRCUITS["sbox8_x8"]] + [(1, 70, 3), (64, 65, 66, 67, 68)]
+    n = 3000
+    e0, e1, mts = _two_providers(fa, n, 2, 43)
+    try:
+        circ = fa.build_setup_circuit(luts)
+        rng = np.random.default_rng(18)
+        in0 = rng.integers(0, 2, circ.n_inputs, dtype=np.uint8)
+        in1 = rng.integers(0, 2, circ.n_inputs, dtype=np.uint8)
+        r = lo.run_two_party(luts, in0, in1, mts[0], mts[1])
+        g, p0, p1, tr = r[0], r[2], r[3], r[4]
+        and_ids = [i for i, k in enumerate(g.kind) if k == "and"]
+        c0, c1 = fa.AndCircuit(e0, circ, 0), fa.AndCircuit(e1, circ, 1)
+        # (a) eval + next message in one call, messages through the host
+        c0.set_inputs(in0)
+        c1.set_inputs(in1)
+        m0, m1 = c0.layer_msg(0), c1.layer_msg(0)
+        for layer in range(circ.n_layers):
+            (od0, oe0), (od1, oe1), _ = tr[layer]
+            assert np.array_equal(m0[0], od0) and np.array_equal(m0[1], oe0) and np.array_equal(m1[0], od1) and \
+                np.array_equal(m1[1], oe1), "messages of layer %d differ from the oracle" % layer
+            n0 = c0.layer_eval_msg(layer, *m1)
+            n1 = c1.layer_eval_msg(layer, *m0)
+            m0, m1 = n0, n1
+        assert m0 is None and m1 is None
+        for c, p in ((c0, p0), (c1, p1)):
+            assert np.array_equal(c.values()[circ.n_inputs:], p.out[and_ids]), "eval_msg path: values differ from the oracle"
+        assert e0.lib.sot_mt_remaining(e0.h) == n - circ.n_gates
+        with pytest.raises(SotError):  # nothing pending any more
+            c0.layer_eval_msg(0, np.zeros(8, np.uint8), np.zeros(8, np.uint8))
+        # (b) all layers of both parties in one call, on fresh stores so that the triples are the oracle's again
+        c0.close()
+        c1.close()
+    finally:
+        e0.close()
+        e1.close()
+    e0, e1, mts = _two_providers(fa, n, 2, 43)
+    try:
+        c0, c1 = fa.AndCircuit(e0, circ, 0), fa.AndCircuit(e1, circ, 1)
+        c0.set_inputs(in0)
+        c1.set_inputs(in1)
+        assert e0.lib.sot_and_circ_run_layers_peer(c0.h, c0.h, 0, 0) != 0  # one circuit twice
+        c0.run_layers_with(c1, 0, 2)  # in two pieces: layers 0..2, then the rest
+        c0.run_layers_with(c1, 3)
+        for c, p in ((c0, p0), (c1, p1)):
+            assert np.array_equal(c.values()[circ.n_inputs:], p.out[and_ids]), "run_layers_peer: values differ from the oracle"
+        assert e0.lib.sot_mt_remaining(e0.h) == n - circ.n_gates == e1.lib.sot_mt_remaining(e1.h)
+        with pytest.raises(SotError):
+            c0.run_layers_with(c1, 0)  # already evaluated
     finally:
         e0.close()
         e1.close()
