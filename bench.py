@@ -445,7 +445,7 @@ def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
     # the peer's TreeGrps for direction Y (received over mpc_channel in the reference), for the tree sets this rank expands
     tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, args.threads)
     pts = eng.points(y[2])
-    pipe = fd.ShardedPipeline(eng)
+    pipe = fd.ShardedPipeline(eng, ordered=not args.no_ordered, overlap=not args.no_overlap)
     xch = {"ms": 0.0, "on": False}
     base_exchange = pipe.exchange
 
@@ -468,7 +468,7 @@ def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
         res["mt"] = pipe.mt_bits(delta, gather=not args.no_gather)
 
     def barrier():
-        eng.sync()
+        pipe.sync()
         torch.cuda.synchronize()
         fd.barrier(world)
 
@@ -533,6 +533,8 @@ def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
                                        info.rows_per_rank, info.chunk, info.x1_bytes_per_peer, info.x2_bytes_per_peer,
                                        "" if not args.no_gather else " (skipped)")},
             "sharded_equals_one_gpu": verified,
+            "pipeline": {"stream_ordered": pipe.ordered, "exchange1_sender_half_overlapped": pipe.overlap,
+                         "host_syncs_per_step": 1 if pipe.ordered else 8},
         }
         if prof:
             per_step = {k: (ms / args.steps, cnt // args.steps) for k, (ms, cnt) in prof.items()}
@@ -554,6 +556,7 @@ def strong_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
                              "exchanges_wall_ms": xch["ms"] / args.steps}
             out["kernels_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}
         print(json.dumps(out), flush=True)
+    pipe.close()
     eng.close()
     dist.destroy_process_group()
     if verified is False:  # a number from a wrong result is no number
@@ -587,6 +590,11 @@ def main():
     ap.add_argument("--split", choices=("auto", "rows", "roles"), default="auto",
                     help="strong mode: rows = bit rows of both roles sharded over the ranks (2, 4, 8 ranks), roles = one "
                          "direction per GPU (2 ranks; auto picks it there: nothing of the expansion crosses the link)")
+    ap.add_argument("--no-ordered", action="store_true",
+                    help="strong mode: every stage call waits for the GPU (round 2's behaviour) instead of the stream-ordered pipeline")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="strong mode: exchange #1 as one all-to-all after both expansions instead of the sender's half "
+                         "travelling while the receiver's trees expand")
     ap.add_argument("--no-verify", action="store_true",
                     help="strong mode: skip the bit-for-bit check of the gathered MT words against a one-GPU context")
     args = ap.parse_args()

@@ -81,6 +81,8 @@ extern "C" {
     pub fn sot_ctx_device_bytes(ctx: *const SotCtx) -> u64;
     pub fn sot_ctx_sync(ctx: *mut SotCtx) -> c_int;
     pub fn sot_ctx_stream(ctx: *mut SotCtx) -> *mut c_void;
+    pub fn sot_ctx_set_stream(ctx: *mut SotCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn sot_ctx_set_async(ctx: *mut SotCtx, on: c_int) -> c_int;
     pub fn sot_treegrp_sums_blocks(c: *const SotConf) -> usize;
     pub fn sot_treegrp_last_blocks(c: *const SotConf) -> usize;
     pub fn sot_sender_expand(ctx: *mut SotCtx, base_ots: *const c_void, delta: *const c_void, seed: *const c_void, num_threads: u64, tg_sums_out: *mut c_void, tg_last_out: *mut c_void) -> c_int;
@@ -99,6 +101,7 @@ extern "C" {
     pub fn sot_ctx_create_sharded(n: u64, scaler: u64, device: c_int, rank: u32, world: u32, ggm_replicated: c_int, out: *mut *mut SotCtx) -> c_int;
     pub fn sot_shard_info_get(ctx: *const SotCtx, out: *mut SotShardInfo) -> c_int;
     pub fn sot_shard_pack_leaves(ctx: *mut SotCtx, send_dev: *mut c_void) -> c_int;
+    pub fn sot_shard_pack_leaves_role(ctx: *mut SotCtx, send_dev: *mut c_void, roles: u32) -> c_int;
     pub fn sot_shard_unpack_leaves(ctx: *mut SotCtx, recv_dev: *const c_void) -> c_int;
     pub fn sot_shard_local_leaves(ctx: *mut SotCtx) -> c_int;
     pub fn sot_shard_qc_encode(ctx: *mut SotCtx, points: *const u64, npoints: u64, send_dev: *mut c_void) -> c_int;

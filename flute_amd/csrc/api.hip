@@ -165,6 +165,13 @@ extern "C" int sot_receiver_points(const sot_conf *c, const uint8_t *choices, ui
     return SOT_OK;
 }
 
+#define CHECK_CTX_EARLY(c)                \
+    if (!(c)) {                           \
+        sot_set_error("null context");    \
+        return SOT_EINVAL;                \
+    }                                     \
+    std::lock_guard<std::recursive_mutex> _lk((c)->mu)
+
 // ---------------------------------------------------------------- context
 int dev_alloc(sot_ctx *c, void **p, uint64_t bytes) {
     *p = nullptr;
@@ -174,6 +181,25 @@ int dev_alloc(sot_ctx *c, void **p, uint64_t bytes) {
         return SOT_ENOMEM;
     }
     c->dev_bytes += bytes;
+    return SOT_OK;
+}
+
+int stage_h2d(sot_ctx *c, void *dst_dev, const void *src_host, uint64_t bytes) {
+    if (!c->async || bytes > c->h_stage_bytes) {  // a pageable source: the runtime stages it before the call returns
+        SOT_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        if (c->async) SOT_HIP(hipStreamSynchronize(c->stream));
+        return SOT_OK;
+    }
+    const uint64_t need = (bytes + 63) & ~63ull;
+    if (c->h_stage_off + need > c->h_stage_bytes) {
+        SOT_HIP(hipEventSynchronize(c->stage_done));  // every copy out of the ring so far (recorded behind the last one)
+        c->h_stage_off = 0;
+    }
+    char *h = (char *)c->h_stage + c->h_stage_off;
+    memcpy(h, src_host, bytes);
+    c->h_stage_off += need;
+    SOT_HIP(hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, c->stream));
+    SOT_HIP(hipEventRecord(c->stage_done, c->stream));
     return SOT_OK;
 }
 
@@ -190,7 +216,9 @@ extern "C" void sot_ctx_destroy(sot_ctx *c) {
         if (p) (void)hipFree(p);
     prof_resolve(c);
     for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->stage_done) (void)hipEventDestroy(c->stage_done);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -239,7 +267,9 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
         return SOT_EINVAL;
     }
     rc = hipSetDevice(device) == hipSuccess ? SOT_OK : SOT_EDEVICE;
-    if (rc == SOT_OK && hipStreamCreate(&c->stream) != hipSuccess) rc = SOT_EDEVICE;
+    if (rc == SOT_OK && hipStreamCreate(&c->own_stream) != hipSuccess) rc = SOT_EDEVICE;
+    c->stream = c->own_stream;
+    if (rc == SOT_OK && hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming) != hipSuccess) rc = SOT_EDEVICE;
     uint64_t nw = (cf.n + 63) / 64;
     uint64_t vblocks = cf.cols * 128;
     uint64_t lvl_blocks = cf.parts << (cf.depth - 1);
@@ -266,6 +296,13 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
     c->tmp_bytes = vblocks * 16 > cf.n * 32 ? vblocks * 16 : cf.n * 32;
     A(c->d_tmp, c->tmp_bytes);
 #undef A
+    // base OTs + choices + the peer's TreeGrps: receiver_expand's host inputs, staged here when the context is stream-ordered
+    c->h_stage_bytes = 4 * (cf.base_ot_count * 17 + (sot_treegrp_sums_blocks(&cf) + sot_treegrp_last_blocks(&cf)) * 16 + cf.parts * 8 + 512);
+    if (rc == SOT_OK && hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault) != hipSuccess) {
+        sot_set_error("hipHostMalloc(%llu bytes) failed", (unsigned long long)c->h_stage_bytes);
+        rc = SOT_ENOMEM;
+    }
+    if (rc == SOT_OK && hipEventRecord(c->stage_done, c->stream) != hipSuccess) rc = SOT_EDEVICE;
     if (rc == SOT_OK) rc = qc_init(c);
     if (rc != SOT_OK) {
         sot_ctx_destroy(c);
@@ -289,6 +326,21 @@ extern "C" int sot_ctx_sync(sot_ctx *c) {
     return SOT_OK;
 }
 extern "C" void *sot_ctx_stream(sot_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int sot_ctx_set_stream(sot_ctx *c, void *stream) {
+    CHECK_CTX_EARLY(c);
+    SOT_HIP(hipSetDevice(c->device));
+    prof_resolve(c);
+    SOT_HIP(hipStreamSynchronize(c->stream));  // nothing of this context is left on the old stream
+    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    return SOT_OK;
+}
+extern "C" int sot_ctx_set_async(sot_ctx *c, int on) {
+    CHECK_CTX_EARLY(c);
+    SOT_HIP(hipSetDevice(c->device));
+    if (!on) SOT_HIP(hipStreamSynchronize(c->stream));
+    c->async = on != 0;
+    return SOT_OK;
+}
 
 // every entry point that takes a context holds its lock for the whole call (see sot_ctx::mu)
 #define CHECK_CTX(c)                      \
@@ -448,7 +500,7 @@ extern "C" int sot_mt_bits_to_device(sot_ctx *c, void *dst_device, uint64_t dst_
     }
     SOT_HIP(hipSetDevice(c->device));
     SOT_HIP(hipMemcpyAsync(dst_device, c->d_mt, bytes, hipMemcpyDeviceToDevice, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     return SOT_OK;
 }
 
@@ -479,7 +531,7 @@ extern "C" int sot_blocks_to_device(sot_ctx *c, int what, const void *delta, voi
     }
     SOT_HIP(hipSetDevice(c->device));
     SOT_HIP(hipMemcpyAsync(dst_device, c->role[role].enc, bytes, hipMemcpyDeviceToDevice, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     return SOT_OK;
 }
 

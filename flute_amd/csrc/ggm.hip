@@ -599,10 +599,10 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
         }
     const uint32_t tr0 = 8 * c->ggm_set0, tr1 = 8 * (c->ggm_set0 + c->ggm_nsets);
     const dim3 gt((tr1 - tr0 + 127) / 128), bt(128);
-    SOT_HIP(hipMemcpyAsync(c->d_base, base_ots, cf.base_ot_count * 16, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(c->d_choices, choices, cf.base_ot_count, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(c->d_tg_sums, tg_sums, sot_treegrp_sums_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
-    SOT_HIP(hipMemcpyAsync(c->d_tg_last, tg_last, sot_treegrp_last_blocks(&cf) * 16, hipMemcpyHostToDevice, c->stream));
+    SOT_TRY(stage_h2d(c, c->d_base, base_ots, cf.base_ot_count * 16));
+    SOT_TRY(stage_h2d(c, c->d_choices, choices, cf.base_ot_count));
+    SOT_TRY(stage_h2d(c, c->d_tg_sums, tg_sums, sot_treegrp_sums_blocks(&cf) * 16));
+    SOT_TRY(stage_h2d(c, c->d_tg_last, tg_last, sot_treegrp_last_blocks(&cf) * 16));
     SOT_HIP(hipMemsetAsync(c->sums, 0, cf.depth * c->nsets * 16 * sizeof(blk_t), c->stream));
     blk_t *V = c->role[SOT_ROLE_RECEIVER].V;
     SOT_LAUNCH(c, KID_RECV_INIT, k_recv_init, gt, bt, c->d_base, c->d_choices, c->d_tg_sums, (uint32_t)cf.parts,
@@ -611,7 +611,7 @@ int ggm_receiver_expand(sot_ctx *c, const void *base_ots, const uint8_t *choices
     SOT_LAUNCH(c, KID_RECV_LAST, k_recv_last, gt, bt, c->d_base, c->d_choices, c->d_tg_last,
                        c->sums + (cf.depth - 1) * c->nsets * 16, (uint32_t)cf.parts, (uint32_t)cf.depth, cf.cols, V, tr0, tr1);
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     c->role[SOT_ROLE_RECEIVER].expanded = true;
     c->role[SOT_ROLE_RECEIVER].encoded = false;
     c->sh.slots_ready = c->sh.enc_slots_ready = false;
@@ -678,7 +678,8 @@ int hash_sender(sot_ctx *c, const void *delta, void *msgs_out, blk_t *dst_dev) {
                        c->role[SOT_ROLE_SENDER].enc, d, c->n_out, dst_dev);
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, dst_dev, c->n_out * 32, hipMemcpyDeviceToHost, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    if (msgs_out) SOT_HIP(hipStreamSynchronize(c->stream));
+    else SOT_SYNC(c);
     return SOT_OK;
 }
 
@@ -703,7 +704,8 @@ int hash_receiver(sot_ctx *c, void *msgs_out, uint64_t *choices_out, blk_t *dst_
     SOT_HIP(hipGetLastError());
     if (msgs_out) SOT_HIP(hipMemcpyAsync(msgs_out, dst_dev, c->n_out * 16, hipMemcpyDeviceToHost, c->stream));
     if (choices_out) SOT_HIP(hipMemcpyAsync(choices_out, c->d_chw, nw * 8, hipMemcpyDeviceToHost, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    if (msgs_out || choices_out) SOT_HIP(hipStreamSynchronize(c->stream));
+    else SOT_SYNC(c);
     return SOT_OK;
 }
 
@@ -724,7 +726,7 @@ int hash_mt_role_bits(sot_ctx *c, int role, const void *delta, uint64_t *dst_dev
     SOT_LAUNCH(c, KID_MT_BITS, k_mt_role_bits, dim3(grid_for(c->n_out, HASH_BLOCK, 2048)), dim3(HASH_BLOCK), c->role[role].enc,
                role == SOT_ROLE_SENDER ? 1 : 0, d, c->n_out, dst_device, dst_device + nw);
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     return SOT_OK;
 }
 
@@ -750,7 +752,8 @@ int hash_mt_bits(sot_ctx *c, const void *delta, uint64_t *a, uint64_t *b, uint64
     if (a) SOT_HIP(hipMemcpyAsync(a, c->d_mt, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (b) SOT_HIP(hipMemcpyAsync(b, c->d_mt + nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (cc) SOT_HIP(hipMemcpyAsync(cc, c->d_mt + 2 * nw, nw * 8, hipMemcpyDeviceToHost, c->stream));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    if (a || b || cc) SOT_HIP(hipStreamSynchronize(c->stream));
+    else SOT_SYNC(c);
     return SOT_OK;
 }
 

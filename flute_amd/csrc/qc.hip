@@ -2817,7 +2817,7 @@ void qc_free(sot_ctx *c) {
 // noise indicator bit vector sb (one bit per leaf Block) from the receiver's interleaved points
 static int qc_set_points(sot_ctx *c, const uint64_t *points, uint64_t npoints) {
     const uint64_t nV = c->conf.cols * 128;
-    SOT_HIP(hipMemcpyAsync(c->d_points, points, npoints * 8, hipMemcpyHostToDevice, c->stream));
+    SOT_TRY(stage_h2d(c, c->d_points, points, npoints * 8));
     SOT_HIP(hipMemsetAsync(c->sbv, 0, (nV / 32 + 2) * 4, c->stream));
     SOT_LAUNCH(c, KID_CLEAR_LSB, k_set_points, dim3((npoints + 127) / 128), dim3(128), c->sbv, c->d_points,
                (uint32_t)npoints, nV);
@@ -2894,7 +2894,7 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, in
         sb = c->sbv;
     }
     SOT_TRY(qc_encode_core(c, c->role[role].V, sb, 0, c->role[role].enc));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     c->role[role].encoded = true;
     if (role == SOT_ROLE_RECEIVER) c->recv_unpacked = !packed;
     return SOT_OK;
@@ -2912,7 +2912,7 @@ int qc_encode_slots(sot_ctx *c, const uint64_t *points, uint64_t npoints, blk_t 
     }
     // 2 x rpr live bits per output: whole Blocks at 2 ranks, 8 bytes at 4, 4 bytes at 8
     SOT_TRY(qc_encode_core(c, c->sh.W, sb, c->sh.rpr, out, c->sh.rpr >= 64 ? 4 : c->sh.rpr >= 32 ? 2 : 1));
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     return SOT_OK;
 }
 

@@ -87,10 +87,12 @@ __device__ __forceinline__ void sets_of(uint32_t nsets, uint32_t world, uint32_t
 // exchange #1, sending side. Message for peer q: [role(2)][k < nk][sl < nl_max][j < 128] slices; entry (k, sl, j) is
 // the leaf Block V[128 c + j] of tile c = set0 + sl + nsets k. Entries with sl >= nl or c >= cols are not written
 // (the receiving side skips the same entries).
+// roles: bit 0 = the sender's leaves V0, bit 1 = the receiver's V1 (the two halves of a message can be packed and sent
+// separately: the sender's slices travel while the receiver's trees still expand)
 template <int LW>
 __global__ void __launch_bounds__(256)
     k_pack_leaves(const blk_t *__restrict__ V0, const blk_t *__restrict__ V1, shard_geom g, unsigned char *__restrict__ send,
-                  uint64_t x1_bytes) {
+                  uint64_t x1_bytes, uint32_t roles) {
     typedef typename slice_ops<LW>::T T;
     uint32_t set0, nl;
     sets_of(g.nsets, g.world, g.rank, set0, nl);
@@ -102,13 +104,16 @@ __global__ void __launch_bounds__(256)
         const uint64_t k = t / nl;
         const uint64_t c = set0 + sl + (uint64_t)g.nsets * k;
         if (c >= g.cols) continue;
-        const blk_t v0 = V0[128 * c + j], v1 = V1[128 * c + j];
         const uint64_t lc = (k * g.nl_max + sl) * 128 + j;
+        if (roles & 1u) {
+            const blk_t v0 = V0[128 * c + j];
 #pragma unroll
-        for (uint32_t q = 0; q < (1u << LW); q++) {
-            T *dst = (T *)(send + q * x1_bytes);
-            dst[lc] = slice_ops<LW>::get(v0, q);
-            dst[rs + lc] = slice_ops<LW>::get(v1, q);
+            for (uint32_t q = 0; q < (1u << LW); q++) ((T *)(send + q * x1_bytes))[lc] = slice_ops<LW>::get(v0, q);
+        }
+        if (roles & 2u) {
+            const blk_t v1 = V1[128 * c + j];
+#pragma unroll
+            for (uint32_t q = 0; q < (1u << LW); q++) ((T *)(send + q * x1_bytes))[rs + lc] = slice_ops<LW>::get(v1, q);
         }
     }
 }
@@ -274,31 +279,33 @@ extern "C" int sot_shard_info_get(const sot_ctx *c, sot_shard_info *o) {
     return SOT_OK;
 }
 
-static int need_expanded(sot_ctx *c) {
-    if (!c->role[0].expanded || !c->role[1].expanded) {
+static int need_expanded(sot_ctx *c, uint32_t roles = 3) {
+    if (((roles & 1u) && !c->role[0].expanded) || ((roles & 2u) && !c->role[1].expanded)) {
         sot_set_error("sharded context: both the sender and the receiver instance must be expanded first");
         return SOT_ESTATE;
     }
     return SOT_OK;
 }
 
-extern "C" int sot_shard_pack_leaves(sot_ctx *c, void *send_dev) {
+extern "C" int sot_shard_pack_leaves_role(sot_ctx *c, void *send_dev, uint32_t roles);
+extern "C" int sot_shard_pack_leaves(sot_ctx *c, void *send_dev) { return sot_shard_pack_leaves_role(c, send_dev, 3u); }
+extern "C" int sot_shard_pack_leaves_role(sot_ctx *c, void *send_dev, uint32_t roles) {
     SHARD_CTX(c);
-    if (!send_dev) return SOT_EINVAL;
+    if (!send_dev || roles < 1 || roles > 3) return SOT_EINVAL;
     if (c->sh.ggm_replicated) {
         sot_set_error("sharded context with a replicated GGM stage has no exchange #1: call sot_shard_local_leaves");
         return SOT_ESTATE;
     }
-    SOT_TRY(need_expanded(c));
+    SOT_TRY(need_expanded(c, roles));
     SOT_HIP(hipSetDevice(c->device));
     const shard_geom g = geom_of(c);
     const unsigned grid = sgrid(g.nk * c->ggm_nsets * 128);
     unsigned char *s = (unsigned char *)send_dev;
-    BY_WORLD(c, SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<1>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes),
-             SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<2>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes),
-             SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<3>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes));
+    BY_WORLD(c, SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<1>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes, roles),
+             SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<2>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes, roles),
+             SOT_LAUNCH(c, KID_SHARD_PACK, k_pack_leaves<3>, dim3(grid), dim3(256), c->role[0].V, c->role[1].V, g, s, c->sh.x1_bytes, roles));
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));  // the collective runs on another stream
+    SOT_SYNC(c);  // the collective runs on another stream, unless the context is stream-ordered on the collective's stream
     return SOT_OK;
 }
 
@@ -309,6 +316,7 @@ extern "C" int sot_shard_unpack_leaves(sot_ctx *c, const void *recv_dev) {
         sot_set_error("sharded context with a replicated GGM stage has no exchange #1: call sot_shard_local_leaves");
         return SOT_ESTATE;
     }
+    SOT_TRY(need_expanded(c));
     SOT_HIP(hipSetDevice(c->device));
     const shard_geom g = geom_of(c);
     const unsigned grid = sgrid((g.nk * g.nl_max * 128) * c->sh.world);
@@ -317,7 +325,7 @@ extern "C" int sot_shard_unpack_leaves(sot_ctx *c, const void *recv_dev) {
              SOT_LAUNCH(c, KID_SHARD_UNPACK, k_unpack_leaves<2>, dim3(grid), dim3(256), r, g, c->sh.x1_bytes, c->sh.W),
              SOT_LAUNCH(c, KID_SHARD_UNPACK, k_unpack_leaves<3>, dim3(grid), dim3(256), r, g, c->sh.x1_bytes, c->sh.W));
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));  // the caller may reuse recv_dev
+    SOT_SYNC(c);  // the caller may reuse recv_dev
     c->sh.slots_ready = true;
     c->sh.enc_slots_ready = false;
     return SOT_OK;
@@ -380,7 +388,7 @@ extern "C" int sot_shard_unpack_encoded(sot_ctx *c, const void *recv_dev) {
              SOT_LAUNCH(c, KID_SHARD_UNPACK, k_unpack_enc<2>, dim3(grid), dim3(256), r, c->sh.chunk, c->sh.n_local, c->role[0].enc, c->role[1].enc),
              SOT_LAUNCH(c, KID_SHARD_UNPACK, k_unpack_enc<3>, dim3(grid), dim3(256), r, c->sh.chunk, c->sh.n_local, c->role[0].enc, c->role[1].enc));
     SOT_HIP(hipGetLastError());
-    SOT_HIP(hipStreamSynchronize(c->stream));
+    SOT_SYNC(c);
     c->role[0].encoded = c->role[1].encoded = true;
     c->recv_unpacked = false;
     return SOT_OK;

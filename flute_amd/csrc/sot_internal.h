@@ -22,6 +22,12 @@ void sot_set_error(const char *fmt, ...);
         }                                                                                       \
     } while (0)
 
+// end of a stage call that hands nothing to the host: wait for the stream unless the context is stream-ordered
+#define SOT_SYNC(c)                                               \
+    do {                                                          \
+        if (!(c)->async) SOT_HIP(hipStreamSynchronize((c)->stream)); \
+    } while (0)
+
 #define SOT_TRY(expr)              \
     do {                           \
         int _rc = (expr);          \
@@ -126,7 +132,12 @@ struct sot_ctx {
     uint32_t opts = 0;
     int device = 0;
     uint32_t num_cus = 256;  // persistent kernels launch one workgroup per CU
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every kernel and copy of this context is queued on
+    hipStream_t own_stream = nullptr;  // created with the context; `stream` is this one unless sot_ctx_set_stream gave another
+    bool async = false;                // sot_ctx_set_async: stage calls that hand nothing to the host do not wait for the stream
+    void *h_stage = nullptr;           // pinned staging ring for small host inputs (stage_h2d, async mode)
+    uint64_t h_stage_bytes = 0, h_stage_off = 0;
+    hipEvent_t stage_done = nullptr;   // recorded behind the last H2D copy out of h_stage
     sot_conf conf;
     qc_geom g;
     uint64_t nsets = 0;  // parts / 8
@@ -209,6 +220,9 @@ int qc_encode_slots(sot_ctx *c, const uint64_t *points, uint64_t npoints, blk_t 
 int qc_debug_row(sot_ctx *c, const uint32_t *row_in, int stage, uint32_t *row_out);
 
 int dev_alloc(sot_ctx *c, void **p, uint64_t bytes);
+// small host input -> device on the context's stream. Stream-ordered contexts (sot_ctx_set_async) copy it through the
+// context's pinned ring first, so that the caller's buffer is free when the call returns although nothing waits for the GPU.
+int stage_h2d(sot_ctx *c, void *dst_dev, const void *src_host, uint64_t bytes);
 
 // ---- shard.hip
 int shard_init(sot_ctx *c, uint32_t rank, uint32_t world, int ggm_replicated);

@@ -145,9 +145,15 @@ def gather_sharded_blocks(engine, what, world, delta=None, buf=None):
 class ShardedPipeline:
     """One rank's side of a sharded precompute_mts step (gmw/src/mul_triple/silent_ot.rs:79-114 for ONE expansion over
     `world` GPUs). `exchange(send, recv)` is the all-to-all: all_to_all_bytes over torch.distributed by default; the
-    single-process tests pass a function that copies between the ranks' buffers instead."""
+    single-process tests pass a function that copies between the ranks' buffers instead.
 
-    def __init__(self, engine, exchange=None, torch_device=None):
+    ordered = True (what bench.py uses): the engine queues its kernels on this pipeline's torch stream
+    (sot_ctx_set_stream) and its stage calls no longer wait for the GPU (sot_ctx_set_async); the collectives are issued
+    under the same stream, so stages and exchanges are ordered by the stream alone -- one host synchronisation per step
+    (the TreeGrp download of the sender's expansion) instead of eight. overlap = True additionally sends the SENDER's
+    leaf slices (half of exchange #1, on a second stream) while the receiver's trees expand."""
+
+    def __init__(self, engine, exchange=None, torch_device=None, ordered=False, overlap=False):
         import torch
         self.eng, self.world = engine, engine.world
         dev = torch_device if torch_device is not None else torch.device("cuda", engine.device)
@@ -160,50 +166,123 @@ class ShardedPipeline:
         nwl = engine.chunk // 64
         self.mt = torch.zeros(3, nwl, dtype=torch.int64, device=dev)
         self.exchange = exchange or (lambda s, r: all_to_all_bytes(s, self.world, r))
+        self.ordered = bool(ordered) and dev.type == "cuda"
+        self.overlap = bool(overlap) and self.ordered and not engine.ggm_replicated
+        self.stream = self.stream2 = None
+        if self.ordered:
+            self.stream, self.stream2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            if self.overlap:  # contiguous staging of one role's halves of the world messages
+                h = engine.world * (engine.x1_bytes // 2)
+                self.half_s = [torch.empty(h, dtype=torch.uint8, device=dev) for _ in range(2)]
+                self.half_r = [torch.empty(h, dtype=torch.uint8, device=dev) for _ in range(2)]
+            torch.cuda.synchronize(dev)  # the buffers above were made on the default stream
+            engine.set_stream(self.stream.cuda_stream)
+            engine.set_async(True)
+
+    def close(self):
+        """hand the engine back its own stream (before the torch streams go away)"""
+        if self.ordered and self.eng.h:
+            self.eng.set_async(False)
+            self.eng.set_stream(None)
+        self.ordered = False
+
+    def _on_stream(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.stream) if self.ordered else contextlib.nullcontext()
 
     def expand(self, sender_base, delta, seed, threads, recv_base, recv_choices, tg_sums, tg_last):
         """both directions' GGM stage on this rank's tree sets; returns this rank's TreeGrps (flat arrays, own groups)"""
-        tg = self.eng.sender_expand(sender_base, delta, seed, threads)
-        self.eng.receiver_expand(recv_base, recv_choices, tg_sums, tg_last)
+        with self._on_stream():
+            tg = self.eng.sender_expand(sender_base, delta, seed, threads)
+            if self.overlap:
+                self._send_role(0)  # the sender's slices travel while the receiver's trees expand
+            self.eng.receiver_expand(recv_base, recv_choices, tg_sums, tg_last)
         return tg
 
+    def _send_role(self, r):
+        """pack role r's halves of the messages of exchange #1 and run their all-to-all: role 0 on the second stream,
+        role 1 on the pipeline's own"""
+        import torch
+        e, w, h = self.eng, self.world, self.eng.x1_bytes // 2
+        e.pack_leaves(self.send1.data_ptr(), roles=1 << r)
+        st = self.stream2 if r == 0 else self.stream
+        if r == 0:
+            self.stream2.wait_stream(self.stream)
+        with torch.cuda.stream(st):
+            self.half_s[r].view(w, h).copy_(self.send1.view(w, 2, h)[:, r])
+            self.exchange(self.half_s[r], self.half_r[r])
+            self.recv1.view(w, 2, h)[:, r].copy_(self.half_r[r].view(w, h))
+
     def exchange_leaves(self):
-        if self.eng.ggm_replicated:
-            self.eng.local_leaves()
-            return
-        self.eng.pack_leaves(self.send1.data_ptr())
-        self.exchange(self.send1, self.recv1)
-        self.sync_exchange()
-        self.eng.unpack_leaves(self.recv1.data_ptr())
+        with self._on_stream():
+            if self.eng.ggm_replicated:
+                self.eng.local_leaves()
+                return
+            if self.overlap:
+                self._send_role(1)
+                self.stream.wait_stream(self.stream2)
+            else:
+                self.eng.pack_leaves(self.send1.data_ptr())
+                self.exchange(self.send1, self.recv1)
+                self.sync_exchange()
+            self.eng.unpack_leaves(self.recv1.data_ptr())
 
     def encode(self, points):
-        self.eng.shard_qc_encode(points, self.send2.data_ptr())
-        self.exchange(self.send2, self.recv2)
-        self.sync_exchange()
-        self.eng.unpack_encoded(self.recv2.data_ptr())
+        with self._on_stream():
+            self.eng.shard_qc_encode(points, self.send2.data_ptr())
+            self.exchange(self.send2, self.recv2)
+            self.sync_exchange()
+            self.eng.unpack_encoded(self.recv2.data_ptr())
 
     def sync_exchange(self):
-        """the collective ran on torch's stream, the engine's kernels run on the context's: order them"""
+        """the collective ran on torch's stream, the engine's kernels run on the context's: order them (nothing to do when
+        the context is stream-ordered on the collective's stream)"""
         import torch
-        if self.recv2.is_cuda:
+        if self.recv2.is_cuda and not self.ordered:
             torch.cuda.current_stream(self.recv2.device).synchronize()
 
     def mt_bits(self, delta, gather=True):
         """fused hashes + MT bits on this rank's outputs; with `gather`, the whole expansion's a | b | c words
         ([3, world * chunk / 64] int64, the first ceil(n / 64) of each row are the MulTriples vectors) on every rank"""
-        self.eng.mt_bits(delta, download=False)
-        nwl = (self.eng.n_out + 63) // 64
-        if nwl:
+        with self._on_stream():
+            self.eng.mt_bits(delta, download=False)
+            nwl = (self.eng.n_out + 63) // 64
+            if nwl:
+                import torch
+                if getattr(self, "_tmp", None) is None or self._tmp.numel() != 3 * nwl:
+                    self._tmp = torch.empty(3 * nwl, dtype=torch.int64, device=self.mt.device)  # once: no per-step allocation
+                    if self.ordered:
+                        torch.cuda.current_stream().synchronize()
+                tmp = self._tmp
+                self.eng.mt_bits_to_device(tmp.data_ptr(), 3 * nwl * 8)
+                self.mt.zero_()
+                self.mt[:, :nwl] = tmp.reshape(3, nwl)
+            else:
+                self.mt.zero_()
+            out = gather_sharded_words(self.mt, self.world) if gather else self.mt
+        self._hand_over()
+        return out
+
+    def _hand_over(self):
+        """results made on the pipeline's stream are about to be used on the caller's: a stream-side wait, no host sync"""
+        if self.ordered:
             import torch
-            if getattr(self, "_tmp", None) is None or self._tmp.numel() != 3 * nwl:
-                self._tmp = torch.empty(3 * nwl, dtype=torch.int64, device=self.mt.device)  # once: no per-step allocation
-            tmp = self._tmp
-            self.eng.mt_bits_to_device(tmp.data_ptr(), 3 * nwl * 8)
-            self.mt.zero_()
-            self.mt[:, :nwl] = tmp.reshape(3, nwl)
-        else:
-            self.mt.zero_()
-        return gather_sharded_words(self.mt, self.world) if gather else self.mt
+            torch.cuda.current_stream(self.mt.device).wait_stream(self.stream)
+
+    def gather_blocks(self, what, delta=None, buf=None):
+        """gather_sharded_blocks on this pipeline's stream: the whole B / A / hashed-message vector on every rank"""
+        with self._on_stream():
+            out = gather_sharded_blocks(self.eng, what, self.world, delta=delta, buf=buf)
+        self._hand_over()
+        return out
+
+    def sync(self):
+        """wait for everything this pipeline has queued"""
+        if self.ordered:
+            self.stream.synchronize()
+            self.stream2.synchronize()
+        self.eng.sync()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ class ShardInfo(C.Structure):
 
 EXPORTS = [
     "sot_last_error", "sot_device_count", "sot_configure", "sot_ctx_create", "sot_ctx_destroy", "sot_ctx_conf",
-    "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
+    "sot_ctx_device_bytes", "sot_ctx_sync", "sot_ctx_stream", "sot_ctx_set_stream", "sot_ctx_set_async", "sot_treegrp_sums_blocks", "sot_treegrp_last_blocks",
     "sot_sender_expand", "sot_receiver_expand", "sot_receiver_points", "sot_download_rT", "sot_qc_encode",
     "sot_qc_encode2", "sot_download_encoded", "sot_sender_hash", "sot_receiver_hash", "sot_mt_bits", "sot_mt_bits_to_device", "sot_blocks_to_device", "sot_mt_role_bits_to_device", "sot_random_silent_send",
     "sot_random_silent_receive", "sot_prof_enable", "sot_prof_reset", "sot_prof_kernels", "sot_prof_name",
@@ -40,7 +40,7 @@ EXPORTS = [
     "sot_and_circ_layer_eval_msg", "sot_and_circ_run_layers_peer",
     "sot_and_circ_values", "sot_lut_online_eval", "sot_lut_online_eval_dev", "sot_mt_remaining", "sot_alsz_receive", "sot_alsz_send", "sot_alsz_receive_noalloc",
     "sot_alsz_noalloc_max_count", "sot_alsz_ctx_create", "sot_alsz_ctx_destroy", "sot_alsz_ctx_receive",
-    "sot_alsz_ctx_send", "sot_alsz_ctx_msgs_dev", "sot_alsz_ctx_u_dev", "sot_alsz_ctx_sync", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves",
+    "sot_alsz_ctx_send", "sot_alsz_ctx_msgs_dev", "sot_alsz_ctx_u_dev", "sot_alsz_ctx_sync", "sot_ctx_create_sharded", "sot_shard_info_get", "sot_shard_pack_leaves", "sot_shard_pack_leaves_role",
     "sot_shard_unpack_leaves", "sot_shard_local_leaves", "sot_shard_qc_encode", "sot_shard_unpack_encoded",
 ]
 
@@ -74,6 +74,8 @@ def load_library():
     L.sot_ctx_sync.argtypes = [P]
     L.sot_ctx_stream.argtypes = [P]
     L.sot_ctx_stream.restype = P
+    L.sot_ctx_set_stream.argtypes = [P, P]
+    L.sot_ctx_set_async.argtypes = [P, i32]
     L.sot_treegrp_sums_blocks.argtypes = [C.POINTER(Conf)]
     L.sot_treegrp_sums_blocks.restype = C.c_size_t
     L.sot_treegrp_last_blocks.argtypes = [C.POINTER(Conf)]
@@ -137,6 +139,7 @@ def load_library():
     L.sot_ctx_create_sharded.argtypes = [u64, u64, i32, C.c_uint32, C.c_uint32, i32, C.POINTER(P)]
     L.sot_shard_info_get.argtypes = [P, C.POINTER(ShardInfo)]
     L.sot_shard_pack_leaves.argtypes = [P, P]
+    L.sot_shard_pack_leaves_role.argtypes = [P, P, C.c_uint32]
     L.sot_shard_unpack_leaves.argtypes = [P, P]
     L.sot_shard_local_leaves.argtypes = [P]
     L.sot_shard_qc_encode.argtypes = [P, P, u64, P]

@@ -134,6 +134,15 @@ class Engine:
     def sync(self):
         check(self.lib.sot_ctx_sync(self.h))
 
+    def set_stream(self, hip_stream):
+        """queue this context's work on the caller's hipStream_t (an int handle, e.g. torch.cuda.current_stream().cuda_stream;
+        None: back to the context's own stream)"""
+        check(self.lib.sot_ctx_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_async(self, on=True):
+        """stage calls that hand nothing to the host no longer wait for the stream (sot_ctx_set_async)"""
+        check(self.lib.sot_ctx_set_async(self.h, 1 if on else 0))
+
     # ---- validation hook of the GF(2)[x] product (sot_qc_transform_row)
     def qc_log2_capacity(self):
         return int(self.lib.sot_qc_log2_capacity(self.h))
@@ -310,8 +319,8 @@ class ShardedEngine(Engine):
         self.x1_bytes, self.x2_bytes = int(info.x1_bytes_per_peer), int(info.x2_bytes_per_peer)
         self.groups = range(int(info.set0), int(info.set0) + int(info.nsets_local))  # TreeGrps this rank makes / needs
 
-    def pack_leaves(self, send_ptr):
-        check(self.lib.sot_shard_pack_leaves(self.h, C.c_void_p(send_ptr)))
+    def pack_leaves(self, send_ptr, roles=3):
+        check(self.lib.sot_shard_pack_leaves_role(self.h, C.c_void_p(send_ptr), roles))
 
     def unpack_leaves(self, recv_ptr):
         check(self.lib.sot_shard_unpack_leaves(self.h, C.c_void_p(recv_ptr)))

@@ -81,6 +81,18 @@ int sot_ctx_sync(sot_ctx *ctx);
 /* the hipStream_t this context launches on (for external event timing) */
 void *sot_ctx_stream(sot_ctx *ctx);
 
+/* Stream-ordered use (no counterpart in the reference, whose stages are blocking calls on rayon pools). By default a
+ * context owns a stream and every stage call waits for it before returning. sot_ctx_set_stream(ctx, s) makes the context
+ * queue its kernels and copies on the caller's hipStream_t s (NULL: back to its own) -- e.g. the stream a collective
+ * library orders its work against --, and sot_ctx_set_async(ctx, 1) lets the stage calls that hand nothing to the host
+ * (receiver expand, encode, the sot_shard_* calls, hashes / MT bits without host outputs, the *_to_device copies) return
+ * without waiting: consecutive stages and the collectives between them are then ordered by the stream alone, and a step
+ * of a sharded expansion has one host synchronisation (the TreeGrp download of sot_sender_expand) instead of eight.
+ * Small host inputs are copied through a pinned ring inside the call, so the caller's buffers are free on return. Calls
+ * that return data to the host still wait. sot_ctx_sync waits for everything queued. */
+int sot_ctx_set_stream(sot_ctx *ctx, void *hip_stream);
+int sot_ctx_set_async(sot_ctx *ctx, int on);
+
 /* ---- stage 1: PPRF expansion -------------------------------------------------------------- */
 /* TreeGrp flat layout (pprf.rs:752-757), group g/8 = 0 .. parts/8-1:
  *   tg_sums [grp][keep(2)][d (depth-1)][tree(8)] Blocks,  tg_last [grp][tree(8)][4] Blocks.
@@ -183,6 +195,10 @@ int sot_ctx_create_sharded(uint64_t n, uint64_t scaler, int device, uint32_t ran
 int sot_shard_info_get(const sot_ctx *ctx, sot_shard_info *out);
 /* leaf slices of this rank's tiles for every peer -> send_dev (device, world * x1_bytes_per_peer); synchronous */
 int sot_shard_pack_leaves(sot_ctx *ctx, void *send_dev);
+/* the same for one role's half of every message: roles = 1 the sender's leaves (bytes [0, x1 / 2) of each peer's message),
+ * 2 the receiver's (bytes [x1 / 2, x1)), 3 both -- so that the sender's halves can be exchanged while the receiver's
+ * trees still expand (flute_amd/dist.py::ShardedPipeline, overlap = True) */
+int sot_shard_pack_leaves_role(sot_ctx *ctx, void *send_dev, uint32_t roles);
 /* recv_dev (device, world * x1_bytes_per_peer, message of rank r at r * x1_bytes_per_peer) -> slot Blocks */
 int sot_shard_unpack_leaves(sot_ctx *ctx, const void *recv_dev);
 /* ggm_replicated: cut this rank's rows out of the locally expanded leaves */

@@ -2,7 +2,10 @@
 child process, one per rank): ONE expansion over `world` ranks through torch.distributed -- backend "nccl" = RCCL with
 one GPU per rank, or "gloo" with every rank on GPU 0 (the transport then stages through the host; everything else is the
 same code) -- and rank 0 checks the gathered MT words, B, A and hashed messages bit for bit against a one-GPU context.
-usage: _shard_worker.py <mode shard|roles> <backend> <rank> <world> <port> <n> <replicate 0|1>; exit code 0 = equal."""
+usage: _shard_worker.py <mode shard|roles> <backend> <rank> <world> <port> <n> <replicate 0|1> [ordered 0|1|2]; exit code
+0 = equal. ordered: 0 = every stage call waits for the GPU, 1 = stream-ordered pipeline (sot_ctx_set_stream / _set_async),
+2 = stream-ordered + the sender's half of exchange #1 overlapped with the receiver's expansion; two steps are run so that
+the second one starts while nothing has been waited for."""
 import os
 import sys
 
@@ -15,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     mode, backend = sys.argv[1], sys.argv[2]
     rank, world, port, n, replicate = (int(a) for a in sys.argv[3:8])
+    ordered = int(sys.argv[8]) if len(sys.argv) > 8 else 0
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -62,15 +66,20 @@ def main():
             ok = np.array_equal(got, want["mt"])
     else:
         eng = fa.ShardedEngine(n, rank, world, device=dev, ggm_replicated=bool(replicate))
-        pipe = fd.ShardedPipeline(eng)
-        pipe.expand(x[0], delta, seed, T, y[1], y[2], *tg_y)
-        pipe.exchange_leaves()
-        pipe.encode(eng.points(y[2]))
-        mt = pipe.mt_bits(delta, gather=True).cpu().numpy().view(np.uint64)
+        pipe = fd.ShardedPipeline(eng, ordered=ordered >= 1, overlap=ordered >= 2)
+        pts = eng.points(y[2])
+        for _ in range(2 if ordered else 1):
+            pipe.expand(x[0], delta, seed, T, y[1], y[2], *tg_y)
+            pipe.exchange_leaves()
+            pipe.encode(pts)
+            mt_t = pipe.mt_bits(delta, gather=True)
+        mt = mt_t.cpu().numpy().view(np.uint64)
         outs = {}
         for key, what, dl in (("B", eng.OUT_B, None), ("A", eng.OUT_A, None), ("s", eng.OUT_SENDER_MSGS, delta),
                               ("r", eng.OUT_RECEIVER_MSGS, None)):
-            outs[key] = fd.gather_sharded_blocks(eng, what, world, delta=dl)[0].cpu().numpy().view(np.uint64)
+            outs[key] = pipe.gather_blocks(what, delta=dl)[0].cpu().numpy().view(np.uint64)
+        pipe.sync()
+        pipe.close()
         if rank == 0:
             ok = np.array_equal(mt[:, :want["mt"].shape[1]], want["mt"])
             for key in outs:

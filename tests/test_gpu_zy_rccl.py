@@ -25,11 +25,11 @@ def _free_port():
     return p
 
 
-def _run(mode, backend, world, n, replicate=0, timeout=240):
+def _run(mode, backend, world, n, replicate=0, ordered=0, timeout=240):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), mode, backend, str(r),
-                               str(world), str(port), str(n), str(replicate)], env=env, cwd=ROOT)
+                               str(world), str(port), str(n), str(replicate), str(ordered)], env=env, cwd=ROOT)
              for r in range(world)]
     rcs = []
     try:
@@ -47,9 +47,12 @@ def _gpus():
     return torch.cuda.device_count()  # counting devices does not initialise the GPU
 
 
-@pytest.mark.parametrize("world,n,replicate", [(2, 1 << 20, 0), (4, 100003, 0), (2, 40000, 1)])
-def test_sharded_step_multiprocess_gloo_one_gpu(world, n, replicate):
-    _run("shard", "gloo", world, n, replicate)
+@pytest.mark.parametrize("world,n,replicate,ordered", [(2, 1 << 20, 0, 0), (4, 100003, 0, 1), (2, 40000, 1, 1),
+                                                       (4, 1 << 20, 0, 2), (8, 3 * 2 ** 20 + 12345, 0, 2)])
+def test_sharded_step_multiprocess_gloo_one_gpu(world, n, replicate, ordered):
+    """ordered 1 / 2: the stream-ordered pipeline bench.py uses (no host waits between the stages; 2: the sender's half of
+    exchange #1 on a second stream while the receiver's trees expand)"""
+    _run("shard", "gloo", world, n, replicate, ordered)
 
 
 def test_role_split_multiprocess_gloo_one_gpu():
@@ -61,8 +64,9 @@ def test_sharded_step_over_rccl():
     if g < 2:
         pytest.skip("RCCL needs one GPU per rank: %d GPU visible (the gloo variants above run the same pipeline code)" % g)
     world = 8 if g >= 8 else 4 if g >= 4 else 2
-    _run("shard", "nccl", world, 1 << 20)
-    _run("shard", "nccl", 2, 1 << 20, replicate=1)
+    _run("shard", "nccl", world, 1 << 20, ordered=2)  # what bench.py --gpus N runs
+    _run("shard", "nccl", world, 1 << 20, ordered=0)
+    _run("shard", "nccl", 2, 1 << 20, replicate=1, ordered=1)
 
 
 def test_role_split_over_rccl():
