@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "aes_dev.h"
+#include "bitmat_dev.h"
 #include "sot_internal.h"
 
 #define AZ_THREADS 1024
@@ -29,7 +30,7 @@ __global__ void __launch_bounds__(AZ_THREADS)
            uint64_t nj, uint64_t count, blk_t *__restrict__ out) {
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ uint32_t keys[128 * (SENDER ? 1 : 2) * 44];
-    __shared__ uint32_t tile[AZ_TILES][128][5];  // padded rows
+    __shared__ uint32_t xch[AZ_TILES][512];  // word exchange of the tile transposes (bitmat_dev.h)
     aes_lds_fill(te);
     for (uint32_t i = threadIdx.x; i < 128 * (SENDER ? 1 : 2) * 44; i += AZ_THREADS) keys[i] = rks[i];
     __syncthreads();
@@ -38,6 +39,7 @@ __global__ void __launch_bounds__(AZ_THREADS)
     const uint32_t rbit = SENDER ? base_choice[r] : 0;
     for (uint64_t j0 = (uint64_t)blockIdx.x * AZ_TILES; j0 < nj; j0 += (uint64_t)gridDim.x * AZ_TILES) {
         const uint64_t j = j0 + tl;
+        uint32_t w[4] = {0, 0, 0, 0};
         if (j < nj) {
             const blk_t ctr = make_uint4((uint32_t)j, (uint32_t)(j >> 32), 0, 0);
             blk_t t = aes_encrypt<true>(te, k0, ctr);
@@ -47,23 +49,14 @@ __global__ void __launch_bounds__(AZ_THREADS)
                 const blk_t u = bxor(bxor(aes_encrypt<true>(te, k0 + 44, ctr), t), choices[j]);  // :212-217
                 U[(uint64_t)r * nj + j] = u;
             }
-            tile[tl][r][0] = t.x, tile[tl][r][1] = t.y, tile[tl][r][2] = t.z, tile[tl][r][3] = t.w;
+            w[0] = t.x, w[1] = t.y, w[2] = t.z, w[3] = t.w;
         }
-        __syncthreads();
+        // OT i = 128 j + r: bit q of its Block = bit r of row q -- the 128 x 128 bit transpose of the tile, in registers
+        bm_transpose128(w, xch[tl], r);
         if (j < nj) {
-            // OT i = 128 j + r: bit q of its Block = bit r of row q
-            const uint32_t rw = r >> 5, rb = r & 31;
-            uint32_t o[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t w = 0;
-#pragma unroll 8
-                for (int b = 0; b < 32; b++) w |= ((tile[tl][32 * q + b][rw] >> rb) & 1u) << b;
-                o[q] = w;
-            }
             const uint64_t i = 128 * j + r;
             if (i < count) {
-                const blk_t x = make_uint4(o[0], o[1], o[2], o[3]);
+                const blk_t x = make_uint4(w[0], w[1], w[2], w[3]);
                 if (SENDER) {
                     out[2 * i] = cr_hash(te, x);
                     out[2 * i + 1] = cr_hash(te, bxor(x, delta));

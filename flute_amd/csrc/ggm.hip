@@ -8,6 +8,7 @@
 //                          rT[r][col] bit j == V[128*col + j] bit r. The QC stage consumes V directly.
 //   sums                 : [level][set][keep][tree%8] Blocks
 #include "aes_dev.h"
+#include "bitmat_dev.h"
 #include "sot_internal.h"
 #include <string.h>
 
@@ -325,25 +326,13 @@ __global__ void k_recv_last(const blk_t *__restrict__ base, const uint8_t *__res
 __global__ void __launch_bounds__(128)
     k_transpose_tiles(const blk_t *__restrict__ in, uint64_t in_estride, uint64_t in_tstride, blk_t *__restrict__ out,
                       uint64_t out_estride, uint64_t out_tstride, uint64_t ntiles) {
-    __shared__ uint32_t tile[128][5];  // padded rows
+    __shared__ uint32_t xch[512];
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint32_t j = threadIdx.x;
-        blk_t v = in[t * in_tstride + (uint64_t)j * in_estride];
-        tile[j][0] = v.x;
-        tile[j][1] = v.y;
-        tile[j][2] = v.z;
-        tile[j][3] = v.w;
-        __syncthreads();
-        const uint32_t r = threadIdx.x, rw = r >> 5, rb = r & 31;
-        uint32_t o[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t w = 0;
-#pragma unroll 8
-            for (int b = 0; b < 32; b++) w |= ((tile[32 * q + b][rw] >> rb) & 1u) << b;
-            o[q] = w;
-        }
-        out[t * out_tstride + (uint64_t)r * out_estride] = make_uint4(o[0], o[1], o[2], o[3]);
+        const uint32_t r = threadIdx.x;
+        const blk_t v = in[t * in_tstride + (uint64_t)r * in_estride];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        bm_transpose128(w, xch, r);  // registers + a 4 x 4 word exchange through LDS (bitmat_dev.h)
+        out[t * out_tstride + (uint64_t)r * out_estride] = make_uint4(w[0], w[1], w[2], w[3]);
         __syncthreads();
     }
 }
