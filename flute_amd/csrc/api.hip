@@ -247,7 +247,8 @@ extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx *
             const char *name;
             uint32_t bit;
         } sw[] = {{"SOT_NO_TOP", SOT_OPT_NO_TOP},         {"SOT_NO_ASPLIT", SOT_OPT_NO_ASPLIT},   {"SOT_NO_WU", SOT_OPT_NO_WU},
-                  {"SOT_NO_W32PAIR", SOT_OPT_NO_W32PAIR}, {"SOT_NO_GGM_TOP", SOT_OPT_NO_GGM_TOP}};
+                  {"SOT_NO_W32PAIR", SOT_OPT_NO_W32PAIR}, {"SOT_NO_GGM_TOP", SOT_OPT_NO_GGM_TOP},
+                  {"SOT_NO_LUT_COOP", SOT_OPT_NO_LUT_COOP}};
         for (auto &e : sw)
             if (getenv(e.name)) c->opts |= e.bit;
     }

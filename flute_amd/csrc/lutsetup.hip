@@ -520,6 +520,104 @@ __global__ void __launch_bounds__(256)
     out[idx] = (uint8_t)((acc ^ lam_out[idx]) & 1u);
 }
 
+// The same computation, workgroup-cooperative (round 3): a workgroup takes `ipb` consecutive instances and
+//   1. stages each instance's setup shares -- its n_in input bits and its tcount[l] gate bits of every setup layer, each a
+//      contiguous bit range of the value store -- into LDS as a compact vector (segments padded to whole words: woff);
+//   2. assembles the 2^p-bit vector L (L[s] = share of the product over subset s, L[0] = party) ONCE per (instance, class),
+//      a class being the template gates with the same arity and the same lsrc row (all 8 LUT gates of sbox8.lut: one input
+//      set, one cached subset circuit) -- the words of L are dealt to the class's gates, so a gate gathers 2^p / count bits
+//      from LDS instead of 2^p - 1 bits from HBM;
+//   3. per (instance, gate): the table permuted by m, its zeta transform Z, parity(Z & L) ^ lambda_out.
+// cpos[g][s]: compact bit position of lsrc[g][s]; gcls[g] = class | rank << 16 | min(count, 8) << 24 (rank 255: no words).
+__device__ __forceinline__ uint32_t bits32_at(const uint64_t *__restrict__ w, uint64_t bit) {
+    const uint32_t sh = (uint32_t)(bit & 63);
+    uint64_t v = w[bit >> 6] >> sh;
+    if (sh > 32) v |= w[(bit >> 6) + 1] << (64 - sh);
+    return (uint32_t)v;
+}
+__global__ void __launch_bounds__(256)
+    k_lut_online2(const uint64_t *__restrict__ vals, uint32_t inst0, uint32_t batch, uint32_t n_luts, uint32_t n_in, uint32_t nlay,
+                  const uint32_t *__restrict__ arity, const uint32_t *__restrict__ tt, const uint32_t *__restrict__ cpos,
+                  const uint32_t *__restrict__ gcls, uint32_t ncls, const uint64_t *__restrict__ lbase,
+                  const uint32_t *__restrict__ tcount, const uint32_t *__restrict__ woff, uint32_t CW, uint32_t ipb,
+                  const uint8_t *__restrict__ masked_in, const uint8_t *__restrict__ lam_out, uint32_t party,
+                  uint8_t *__restrict__ out) {
+    extern __shared__ uint32_t lo_sm[];
+    uint32_t *comp = lo_sm, *Lb = lo_sm + ipb * CW;
+    const uint32_t i0 = blockIdx.x * ipb;
+    const uint32_t ni = batch - i0 < ipb ? batch - i0 : ipb;
+    for (uint32_t it = threadIdx.x; it < ni * CW; it += 256) {
+        const uint32_t il = it / CW, cw = it - il * CW;
+        uint32_t sg = 0;
+        while (sg < nlay && woff[sg + 1] <= cw) sg++;
+        const uint32_t c = cw - woff[sg], len = (sg == 0 ? n_in : tcount[sg - 1]) - 32 * c;
+        const uint64_t inst = (uint64_t)inst0 + i0 + il;
+        const uint64_t bit = (sg == 0 ? inst * n_in : lbase[sg - 1] + inst * tcount[sg - 1]) + 32 * c;
+        uint32_t v = bits32_at(vals, bit);
+        if (len < 32) v &= (1u << len) - 1u;
+        comp[it] = v;
+    }
+    __syncthreads();
+    const uint32_t items = ni * n_luts;
+    for (uint32_t it = threadIdx.x; it < items; it += 256) {
+        const uint32_t il = it / n_luts, g = it - il * n_luts;
+        const uint32_t info = gcls[g], cl = info & 0xFFFFu, rk = (info >> 16) & 0xFFu, cn = info >> 24;
+        if (rk == 255u) continue;
+        const uint32_t p = arity[g], nrow = 1u << p, nw = nrow > 32 ? nrow >> 5 : 1, hi = nrow < 32 ? nrow : 32;
+        const uint32_t *cp = cpos + (uint64_t)g * 256;
+        const uint32_t *cv = comp + il * CW;
+        for (uint32_t w = rk; w < nw; w += cn) {
+            uint32_t word = w == 0 ? (party & 1u) : 0u;
+            for (uint32_t b = (w == 0 ? 1 : 0); b < hi; b++) {
+                const uint32_t q = cp[w * 32 + b];
+                word |= ((cv[q >> 5] >> (q & 31)) & 1u) << b;
+            }
+            Lb[(il * ncls + cl) * 8 + w] = word;
+        }
+    }
+    __syncthreads();
+    for (uint32_t it = threadIdx.x; it < items; it += 256) {
+        const uint32_t il = it / n_luts, g = it - il * n_luts;
+        const uint64_t idx = (uint64_t)(i0 + il) * n_luts + g;
+        const uint32_t p = arity[g], nrow = 1u << p, nw = nrow > 32 ? nrow >> 5 : 1;
+        const uint32_t m = masked_in[idx] & (nrow - 1u);
+        uint32_t G[8];
+#pragma unroll
+        for (uint32_t w = 0; w < 8; w++) G[w] = w < nw ? tt[g * 8 + (w ^ (m >> 5))] : 0u;
+#pragma unroll
+        for (uint32_t b = 0; b < 5; b++) {
+            const uint32_t M = b == 0 ? 0x55555555u : b == 1 ? 0x33333333u : b == 2 ? 0x0F0F0F0Fu : b == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+            if ((m >> b) & 1u) {
+#pragma unroll
+                for (uint32_t w = 0; w < 8; w++) G[w] = ((G[w] & M) << (1u << b)) | ((G[w] >> (1u << b)) & M);
+            }
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < 5; b++) {
+            const uint32_t M = b == 0 ? 0x55555555u : b == 1 ? 0x33333333u : b == 2 ? 0x0F0F0F0Fu : b == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+            if (b < p) {
+#pragma unroll
+                for (uint32_t w = 0; w < 8; w++) G[w] ^= (G[w] & M) << (1u << b);
+            }
+        }
+#pragma unroll
+        for (uint32_t wb = 0; wb < 3; wb++) {
+            if (5 + wb < p) {
+#pragma unroll
+                for (uint32_t w = 0; w < 8; w++)
+                    if ((w >> wb) & 1u) G[w] ^= G[w ^ (1u << wb)];
+            }
+        }
+        const uint32_t *L = Lb + (il * ncls + (gcls[g] & 0xFFFFu)) * 8;
+        const uint32_t live = nrow < 32 ? (1u << nrow) - 1u : 0xFFFFFFFFu;
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; w++)
+            if (w < nw) acc ^= G[w] & L[w] & live;
+        out[idx] = (uint8_t)((__popc(acc) ^ lam_out[idx]) & 1u);
+    }
+}
+
 // grows a device buffer kept in the circuit (no allocation once it is large enough)
 static int le_reserve(void **buf, uint64_t *cap, uint64_t bytes) {
     if (*cap >= bytes && *buf) return SOT_OK;
@@ -576,11 +674,20 @@ static int lut_online(sot_and_circ *q, uint32_t first_instance, uint32_t batch, 
     }
     SOT_HIP(hipSetDevice(c->device));
     const uint64_t items = (uint64_t)batch * n_luts;
-    // tables: arity | tt | lsrc | tcount | layer bases, 8-byte aligned pieces in one buffer; items: three byte arrays
+    // tables: arity | tt | lsrc | tcount | layer bases | cpos | gcls | woff, 8-byte aligned pieces in one buffer
+    const uint32_t nlay = q->n_layers;
     const uint64_t o_ar = 0, o_tt = o_ar + (((uint64_t)n_luts * 4 + 7) & ~7ull), o_ls = o_tt + (uint64_t)n_luts * 32;
-    const uint64_t o_tc = o_ls + (uint64_t)n_luts * 1024, o_lb = o_tc + (((uint64_t)q->n_layers * 4 + 7) & ~7ull);
-    const uint64_t tab_bytes = o_lb + (uint64_t)q->n_layers * 8 + 8;
+    const uint64_t o_tc = o_ls + (uint64_t)n_luts * 1024, o_lb = o_tc + (((uint64_t)nlay * 4 + 7) & ~7ull);
+    const uint64_t o_cp = o_lb + (uint64_t)nlay * 8 + 8, o_gc = o_cp + (uint64_t)n_luts * 1024;
+    const uint64_t o_wo = o_gc + (((uint64_t)n_luts * 4 + 7) & ~7ull);
+    const uint64_t tab_bytes = o_wo + (((uint64_t)(nlay + 2) * 4 + 7) & ~7ull);
     SOT_TRY(le_reserve(&q->le_tab, &q->le_tab_bytes, tab_bytes));
+    // compact layout of one instance's shares: the inputs, then every setup layer's gates, each segment padded to words
+    std::vector<uint32_t> woff(nlay + 2, 0);
+    woff[1] = (n_in + 31) / 32;
+    for (uint32_t l = 0; l < nlay; l++) woff[l + 2] = woff[l + 1] + (tcount[l] + 31) / 32;
+    const uint32_t CW = woff[nlay + 1];
+    uint32_t ncls = 0;
     {
         // one host image of the tables; uploaded only when it differs from what the device copy holds (a deeper circuit
         // calls once per LUT layer with the same template: no PCIe traffic but the per-item arrays)
@@ -588,10 +695,28 @@ static int lut_online(sot_and_circ *q, uint32_t first_instance, uint32_t batch, 
         memcpy(img.data() + o_ar, arity, (uint64_t)n_luts * 4);
         memcpy(img.data() + o_tt, tt, (uint64_t)n_luts * 32);
         memcpy(img.data() + o_ls, lsrc, (uint64_t)n_luts * 1024);
-        if (q->n_layers) {
-            memcpy(img.data() + o_tc, tcount, (uint64_t)q->n_layers * 4);
-            memcpy(img.data() + o_lb, q->base.data(), (uint64_t)q->n_layers * 8);
+        if (nlay) {
+            memcpy(img.data() + o_tc, tcount, (uint64_t)nlay * 4);
+            memcpy(img.data() + o_lb, q->base.data(), (uint64_t)nlay * 8);
         }
+        uint32_t *cp = (uint32_t *)(img.data() + o_cp), *gc = (uint32_t *)(img.data() + o_gc);
+        memcpy(img.data() + o_wo, woff.data(), (uint64_t)(nlay + 2) * 4);
+        std::vector<uint32_t> rep, cnt;  // per class: a representative gate, gates so far
+        for (uint32_t g = 0; g < n_luts; g++) {
+            const uint32_t rows = 1u << arity[g];
+            for (uint32_t sx = 1; sx < rows; sx++) {
+                const uint32_t e = lsrc[(uint64_t)g * 256 + sx], l1 = e >> 24, r = e & 0xFFFFFFu;
+                cp[(uint64_t)g * 256 + sx] = 32 * woff[l1] + r;
+            }
+            uint32_t cl = 0;
+            for (; cl < rep.size(); cl++)
+                if (arity[rep[cl]] == arity[g] && !memcmp(lsrc + (uint64_t)rep[cl] * 256 + 1, lsrc + (uint64_t)g * 256 + 1, (rows - 1) * 4)) break;
+            if (cl == rep.size()) rep.push_back(g), cnt.push_back(0);
+            gc[g] = cl | ((cnt[cl] < 8 ? cnt[cl] : 255u) << 16);
+            cnt[cl]++;
+        }
+        ncls = (uint32_t)rep.size();
+        for (uint32_t g = 0; g < n_luts; g++) gc[g] |= (cnt[gc[g] & 0xFFFFu] < 8 ? cnt[gc[g] & 0xFFFFu] : 8u) << 24;
         if (img != q->le_tab_host) {
             SOT_HIP(hipStreamSynchronize(c->stream));  // a kernel of the previous call may still read the old tables
             SOT_HIP(hipMemcpy(q->le_tab, img.data(), tab_bytes, hipMemcpyHostToDevice));
@@ -617,9 +742,20 @@ static int lut_online(sot_and_circ *q, uint32_t first_instance, uint32_t batch, 
         SOT_HIP(hipMemcpyAsync(q->le_items + q->le_cap, lam_out, items, hipMemcpyHostToDevice, c->stream));
         d_m = q->le_items, d_lo = q->le_items + q->le_cap, d_out = q->le_items + 2 * q->le_cap;
     }
-    const uint64_t grid = (items + 255) / 256;
-    hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, first_instance, batch, n_luts, n_in, d_ar, d_tt,
-                       d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);
+    // workgroup-cooperative kernel when `ipb` instances' compact shares and L vectors fit 48 KiB of LDS (any template of a
+    // few hundred gates); otherwise one thread per item gathering from HBM
+    uint32_t ipb = n_luts >= 256 ? 1 : 256 / n_luts;
+    while (ipb > 1 && (uint64_t)ipb * (CW + 8ull * ncls) * 4 > 48 * 1024) ipb /= 2;
+    if ((uint64_t)ipb * (CW + 8ull * ncls) * 4 <= 48 * 1024 && ncls < 65536 && !(c->opts & SOT_OPT_NO_LUT_COOP)) {
+        hipLaunchKernelGGL(k_lut_online2, dim3((batch + ipb - 1) / ipb), dim3(256), ipb * (CW + 8 * ncls) * 4, c->stream, q->vals,
+                           first_instance, batch, n_luts, n_in, nlay, d_ar, d_tt, (const uint32_t *)(tb + o_cp),
+                           (const uint32_t *)(tb + o_gc), ncls, d_lb, d_tc, (const uint32_t *)(tb + o_wo), CW, ipb, d_m, d_lo,
+                           party_id, d_out);
+    } else {
+        const uint64_t grid = (items + 255) / 256;
+        hipLaunchKernelGGL(k_lut_online, dim3((unsigned)grid), dim3(256), 0, c->stream, q->vals, first_instance, batch, n_luts, n_in,
+                           d_ar, d_tt, d_ls, d_lb, d_tc, d_m, d_lo, party_id, d_out);
+    }
     SOT_HIP(hipGetLastError());
     if (!on_device) {
         SOT_HIP(hipMemcpyAsync(delta_share_out, d_out, items, hipMemcpyDeviceToHost, c->stream));

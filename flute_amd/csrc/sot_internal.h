@@ -102,7 +102,8 @@ enum sot_opt {
     SOT_OPT_NO_ASPLIT = 2,   // SOT_NO_ASPLIT: Taylor group A as one tile geometry at R >= 11
     SOT_OPT_NO_WU = 4,       // SOT_NO_WU: whole-unit phases through the generic kernel
     SOT_OPT_NO_W32PAIR = 8,  // SOT_NO_W32PAIR: extra 32-plane passes one row half per workgroup
-    SOT_OPT_NO_GGM_TOP = 16  // SOT_NO_GGM_TOP: every GGM level as its own launch
+    SOT_OPT_NO_GGM_TOP = 16,  // SOT_NO_GGM_TOP: every GGM level as its own launch
+    SOT_OPT_NO_LUT_COOP = 32  // SOT_NO_LUT_COOP: online LUT evaluation one thread per item (k_lut_online) instead of k_lut_online2
 };
 
 // One expansion sharded over `world` GPUs (shard.hip). Rank r owns

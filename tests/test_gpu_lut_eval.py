@@ -99,6 +99,13 @@ def test_sbox8_online_evaluation(fa):
     _check(fa, _sbox8_template(fa), 300, 100000, 5, oracle_instances=(0, 299))
 
 
+def test_online_evaluation_one_thread_per_item_kernel(fa, monkeypatch):
+    """the fallback kernel k_lut_online (templates too large for the cooperative kernel's LDS), selected here by the
+    SOT_NO_LUT_COOP switch that is read at sot_ctx_create: same checks"""
+    monkeypatch.setenv("SOT_NO_LUT_COOP", "1")
+    _check(fa, _sbox8_template(fa), 70, 30000, 6, oracle_instances=(0, 69))
+
+
 def test_mixed_template_online_evaluation(fa):
     """gates of 1 .. 6 inputs, overlapping and permuted input sets (the subset cache and the sorted-input pairing)"""
     rng = np.random.default_rng(3)
