@@ -225,8 +225,8 @@ extern "C" void sot_ctx_destroy(sot_ctx *c) {
 extern "C" int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx **out) {
     if (!out) return SOT_EINVAL;
     *out = nullptr;
-    if (scaler != 2) {
-        sot_set_error("only MultType::QuasiCyclic{scaler: 2} is supported (bench.rs:85)");
+    if (scaler < 2 || scaler > 8) {
+        sot_set_error("MultType::QuasiCyclic{scaler}: 2 (what bench.rs:85 uses) .. 8 supported, got %llu", (unsigned long long)scaler);
         return SOT_EINVAL;
     }
     int ndev = 0;

@@ -12,7 +12,12 @@
 #include "sot_internal.h"
 #include <string.h>
 
+#ifndef GGM_BLOCK
 #define GGM_BLOCK 512  // 8 waves; the 64 KiB AES table allows two workgroups per CU
+#endif
+#ifndef GGM_EXP
+#define GGM_EXP 0  // profiling experiments only (tools/exp_one.sh; results are wrong when set): 1 = levels without their stores
+#endif
 #define HASH_BLOCK 512
 
 // ------------------------------------------------------------------------------------------------
@@ -62,23 +67,30 @@ __global__ void k_aes_ecb(const uint32_t *__restrict__ rk, const blk_t *__restri
 // ------------------------------------------------------------------------------------------------
 // one GGM level for every tree: child[2j+k] = AES_{k_k}(parent[j]) ^ parent[j], per-level XOR sums
 // (pprf.rs:141-194 sender, :388-450 receiver). blockIdx.y = set.
+#if GGM_EXP & 2
+typedef uint32_t ggm_v4 __attribute__((ext_vector_type(4)));
+#define GGM_ST(p, v) __builtin_nontemporal_store((ggm_v4){(v).x, (v).y, (v).z, (v).w}, (ggm_v4 *)(p))
+#else
+#define GGM_ST(p, v) (*(p) = (v))
+#endif
 template <bool LAST>
 __device__ __forceinline__ void ggm_put(blk_t *__restrict__ out, uint32_t set, uint64_t per_set, uint32_t nsets,
                                         uint64_t cols, uint64_t idx, blk_t c0, blk_t c1) {
     const uint64_t node = idx >> 3;
     const uint32_t t8 = idx & 7;
+    if (GGM_EXP & 1) return;
     if (!LAST) {
         blk_t *pout = out + (uint64_t)set * per_set * 2;
-        pout[(2 * node) * 8 + t8] = c0;
-        pout[(2 * node + 1) * 8 + t8] = c1;
+        GGM_ST(&pout[(2 * node) * 8 + t8], c0);
+        GGM_ST(&pout[(2 * node + 1) * 8 + t8], c1);
     } else {
         // leaves 2*node, 2*node+1 live in the same 16-leaf tile
         const uint64_t leaf = 2 * node;
         const uint64_t tile = set + (uint64_t)nsets * (leaf >> 4);
         if (tile < cols) {
             blk_t *pv = out + tile * 128 + 8 * (leaf & 15) + t8;
-            pv[0] = c0;
-            pv[8] = c1;
+            GGM_ST(&pv[0], c0);
+            GGM_ST(&pv[8], c1);
         }
     }
 }

@@ -113,8 +113,9 @@ __device__ __forceinline__ blk_t ld_leaf(const blk_t *__restrict__ V, uint64_t i
 // sb has only `parts` set bits, so that product is a sum of `parts` cyclic shifts of a' = a mod (x^P - 1) -- no
 // transform:  C[k] = [k in S0'] ^ XOR_{s in S1} a'[(k - s) mod P]
 //   S0' = {S mod P : S < nb128} (the b0 half of the row, folded), S1 = {(S - nb128) mod P : nb128 <= S < 2 nb128}
-// (row halves split at Block n_blocks, quasi_cyclic_encode.rs:267; points in the last cols - 2 n_blocks Blocks are
-// outside both halves). pts[i] = pos | kind << 63 (kind 1: an S0' position), ~0 = dropped. One thread per 32 OTs.
+// (row segments split at multiples of Block n_blocks, quasi_cyclic_encode.rs:267; points in the last cols - scaler n_blocks
+// Blocks are outside every segment; with scaler > 2 segment s >= 1 contributes shifts of a_s').
+// pts[i] = pos | (s - 1) << 56 | kind << 63 (kind 1: an S0' position), ~0 = dropped. One thread per 32 OTs.
 #define SC_DROPPED (~0ull)
 __device__ __forceinline__ uint32_t cyc32(const uint32_t *__restrict__ a, uint64_t P, uint64_t start) {
     // bits a'[(start + i) mod P], i < 32; a' has zero bits from P on and two padding words
@@ -127,8 +128,8 @@ __device__ __forceinline__ uint32_t cyc32(const uint32_t *__restrict__ a, uint64
     return v;
 }
 __global__ void __launch_bounds__(256)
-    k_sparse_choice(const uint32_t *__restrict__ a2, uint64_t P, const uint64_t *__restrict__ pts, uint32_t npts, uint64_t n,
-                    uint8_t *__restrict__ C) {
+    k_sparse_choice(const uint32_t *__restrict__ a2, uint64_t a2_stride, uint64_t P, const uint64_t *__restrict__ pts,
+                    uint32_t npts, uint64_t n, uint8_t *__restrict__ C) {
     __shared__ uint64_t sp[256];
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t k0 = 32 * w;
@@ -144,11 +145,11 @@ __global__ void __launch_bounds__(256)
             for (uint32_t i = 0; i < cn; i++) {
                 const uint64_t e = sp[i];
                 if (e == SC_DROPPED) continue;
-                const uint64_t pos = e & ~(1ull << 63);
+                const uint64_t pos = e & ((1ull << 56) - 1);
                 if (e >> 63) {
                     if ((pos >> 5) == w) v ^= 1u << (pos & 31);
-                } else {
-                    v ^= cyc32(a2, P, k0 >= pos ? k0 - pos : k0 + P - pos);
+                } else {  // bits 56..62: s - 1 of the row segment the point lies in, i.e. which public polynomial a_s
+                    v ^= cyc32(a2 + ((e >> 56) & 127u) * a2_stride, P, k0 >= pos ? k0 - pos : k0 + P - pos);
                 }
             }
     }
@@ -2018,16 +2019,16 @@ template <int MODE>
 static void launch_low(sot_ctx *c, uint32_t *Z, const tile_desc &d) {
     const dim3 g((1u << (d.m - 5 - d.nb)) * d.rhalves);
     switch (d.nb) {
-        case 5: hipLaunchKernelGGL((k_fft_low<MODE, 1>), g, dim3(64), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
-        case 6: hipLaunchKernelGGL((k_fft_low<MODE, 2>), g, dim3(128), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
-        case 7: hipLaunchKernelGGL((k_fft_low<MODE, 4>), g, dim3(256), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
-        case 8: hipLaunchKernelGGL((k_fft_low<MODE, 8>), g, dim3(512), 0, c->stream, Z, d, c->TW, c->LM, c->Amat); break;
+        case 5: hipLaunchKernelGGL((k_fft_low<MODE, 1>), g, dim3(64), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur); break;
+        case 6: hipLaunchKernelGGL((k_fft_low<MODE, 2>), g, dim3(128), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur); break;
+        case 7: hipLaunchKernelGGL((k_fft_low<MODE, 4>), g, dim3(256), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur); break;
+        case 8: hipLaunchKernelGGL((k_fft_low<MODE, 8>), g, dim3(512), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur); break;
         default:
             if (MODE == 1 && !QC_EXP && g.x > c->num_cus && !(c->opts & SOT_OPT_NO_TOP)) {
-                hipLaunchKernelGGL(k_fft_low_p, dim3(c->num_cus), dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat, g.x);
+                hipLaunchKernelGGL(k_fft_low_p, dim3(c->num_cus), dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur, g.x);
                 break;
             }
-            hipLaunchKernelGGL((k_fft_low<MODE, 16>), g, dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat);
+            hipLaunchKernelGGL((k_fft_low<MODE, 16>), g, dim3(1024), 0, c->stream, Z, d, c->TW, c->LM, c->Amat_cur);
             break;
     }
 }
@@ -2117,7 +2118,11 @@ template <bool FULL>  // as in k_qc_load
 __global__ void __launch_bounds__(256)
     k_qc_finish(const uint32_t *__restrict__ Z, uint64_t nw, const blk_t *__restrict__ V, const uint32_t *__restrict__ sb,
                 uint32_t sbpos, uint64_t nb128, uint64_t P, uint64_t S, uint32_t tail, uint64_t n, const uint32_t *__restrict__ a2,
-                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out, uint32_t rows_active_, uint32_t out_words_) {
+                const uint32_t *__restrict__ a_hi, blk_t *__restrict__ out, uint32_t rows_active_, uint32_t out_words_,
+                const blk_t *__restrict__ V0, const uint32_t *__restrict__ sb0) {
+    // V / sb: the leaves re-based so that the multiplied segment b_s is "V1" (Blocks [nb128, 2 nb128)): the tail terms read
+    // it. V0 / sb0: the leaves themselves for the b0 terms of the FIRST product (s = 1); nullptr for s >= 2 (scaler > 2),
+    // whose product is XORed into what `out` already holds (quasi_cyclic_encode.rs:265-277: c_poly.add_eq).
     const uint32_t rows_active = FULL ? ROWS : rows_active_, out_words = FULL ? 4u : out_words_;
     __shared__ uint32_t tio[FN_W * 132];  // rows in: [w][row] (stride 129); Blocks out: [w][p][q] (stride 132)
     // sized by the launch (fn_dyn_lds): the kernel is bound by how many workgroups fit a CU, and tail << FN_TAILMAX
@@ -2183,10 +2188,16 @@ __global__ void __launch_bounds__(256)
         if (k >= n) break;
         const uint32_t *sp = tio + (kl >> 5) * 132 + (kl & 31) * 4;
         blk_t r = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-        blk_t u = ld_leaf(V, k, sb, sbpos, out_words);
-        r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
-        if (k + P < nb128) {
-            u = ld_leaf(V, k + P, sb, sbpos, out_words);
+        blk_t u;
+        if (V0) {
+            u = ld_leaf(V0, k, sb0, sbpos, out_words);
+            r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+            if (k + P < nb128) {
+                u = ld_leaf(V0, k + P, sb0, sbpos, out_words);
+                r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
+            }
+        } else {
+            u = ld_leaf(out, k, nullptr, 0, out_words);  // packed like the leaves
             r.x ^= u.x, r.y ^= u.y, r.z ^= u.z, r.w ^= u.w;
         }
         if (tail && !(QC_EXP & 4)) {
@@ -2690,18 +2701,22 @@ static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
     launch_top(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
-static int upload_a_and_transform(sot_ctx *c) {
+// a_s, s = 1 .. scaler - 1: the first n64 u64 of AesRng(seed = Block::from(s)) (init_a_polynomials,
+// quasi_cyclic_encode.rs:127-138), folded mod x^P - 1, its tail bits, and the multiply tables of its transform
+static int upload_a_and_transform(sot_ctx *c, uint32_t sidx) {
     const sot_conf &cf = c->conf;
     const qc_geom &g = c->g;
     const uint64_t nb128 = cf.n_blocks * 128;
-    // a = first n64 u64 of AesRng(seed = Block::from(1)) (quasi_cyclic_encode.rs:127-138)
+    uint32_t *const d_a2 = c->a2 + (uint64_t)(sidx - 1) * c->a2_stride;
+    uint32_t *const d_ahi = c->a_hi + (uint64_t)(sidx - 1) * c->ahi_stride;
+    uint32_t *const d_amat = c->Amat + (uint64_t)(sidx - 1) * c->amat_stride;
     // the raw keystream is staged in Z0 (not yet in use; n_blocks * 16 B is far below its size)
     blk_t *d_araw = (blk_t *)c->Z0;
     if (cf.n_blocks * 16 > g.nw * ROWS * 4) {
         sot_set_error("internal: a does not fit the staging buffer");
         return SOT_EINVAL;
     }
-    uint8_t key[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t key[16] = {(uint8_t)sidx, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     SOT_TRY(util_aes_ctr_device(c, key, 0, d_araw, cf.n_blocks));
     std::vector<uint32_t> a(cf.n_blocks * 4 + 2);
     SOT_HIP(hipMemcpy(a.data(), d_araw, cf.n_blocks * 16, hipMemcpyDeviceToHost));
@@ -2714,24 +2729,25 @@ static int upload_a_and_transform(sot_ctx *c) {
     for (uint64_t i = P; i < nb128; i++)
         if (getbit(i)) ap[(i - P) >> 5] ^= 1u << ((i - P) & 31);
     // tail bits a'[S .. P)
-    c->a_hi_host.assign((g.tail + 31) / 32 + 1, 0);
+    std::vector<uint32_t> ahi((g.tail + 31) / 32 + 1, 0);
     for (uint64_t i = 0; i < g.tail; i++)
-        if ((ap[(g.S + i) >> 5] >> ((g.S + i) & 31)) & 1u) c->a_hi_host[i >> 5] |= 1u << (i & 31);
-    SOT_HIP(hipMemcpy(c->a2, ap.data(), ap.size() * 4, hipMemcpyHostToDevice));
-    SOT_HIP(hipMemcpy(c->a_hi, c->a_hi_host.data(), c->a_hi_host.size() * 4, hipMemcpyHostToDevice));
+        if ((ap[(g.S + i) >> 5] >> ((g.S + i) & 31)) & 1u) ahi[i >> 5] |= 1u << (i & 31);
+    SOT_HIP(hipMemcpy(d_a2, ap.data(), ap.size() * 4, hipMemcpyHostToDevice));
+    SOT_HIP(hipMemcpy(d_ahi, ahi.data(), ahi.size() * 4, hipMemcpyHostToDevice));
     // FFT(a_lo): row 0 of Z
     const fft_plan &plan = *(const fft_plan *)c->qc_plan;
     SOT_HIP(hipMemsetAsync(c->Z0, 0, g.nw * ROWS * 4, c->stream));
     SOT_HIP(hipMemsetAsync(c->Z1, 0, g.nw * ROWS * 4, c->stream));
-    hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw / 2, 256)), dim3(256), 0, c->stream, c->a2, g.lo_bits, g.nw / 2, c->Z0);
+    hipLaunchKernelGGL(k_a_load, dim3(gridn(g.nw / 2, 256)), dim3(256), 0, c->stream, d_a2, g.lo_bits, g.nw / 2, c->Z0);
     uint32_t *zb[2] = {c->Z0, c->Z1};
     int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
     fft_forward_upper(c, zb[cur], plan);
-    hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * LOW_BLK_PLAIN, 256)), dim3(256), 0, c->stream, plan.low,
-                       g.nw / 32, c->TW, c->LM);
+    if (sidx == 1)
+        hipLaunchKernelGGL(k_build_lowmasks, dim3(gridn((g.nw / 32) * 5 * LOW_BLK_PLAIN, 256)), dim3(256), 0, c->stream, plan.low,
+                           g.nw / 32, c->TW, c->LM);
     launch_low<0>(c, zb[cur], plan.low);
     hipLaunchKernelGGL(k_build_amat, dim3(gridn((g.nw / 32) * AMAT_PLAIN, 256)), dim3(256), 0, c->stream, zb[cur], plan.low,
-                       g.nw / 32, c->Amat);
+                       g.nw / 32, d_amat);
     SOT_HIP(hipGetLastError());
     SOT_HIP(hipStreamSynchronize(c->stream));
     return SOT_OK;
@@ -2761,11 +2777,15 @@ int qc_init(sot_ctx *c) {
     g.nw = 1ull << (m - 5);
     SOT_TRY(dev_alloc(c, (void **)&c->Z0, g.nw * ROWS * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->Z1, g.nw * ROWS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->Amat, (g.nw / 32) * AMAT_WORDS * 4));
+    const uint64_t nseg = cf.scaler - 1;  // public polynomials a_1 .. a_{scaler-1}
+    c->amat_stride = (g.nw / 32) * AMAT_WORDS, c->a2_stride = ((cf.P + 31) / 32 + 2 + 3) & ~3ull,
+    c->ahi_stride = (g.tail + 31) / 32 + 1;
+    SOT_TRY(dev_alloc(c, (void **)&c->Amat, nseg * c->amat_stride * 4));
+    c->Amat_cur = c->Amat;
     SOT_TRY(dev_alloc(c, (void **)&c->LM, (g.nw / 32) * 5 * LOW_BLK_WORDS * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->a2, ((cf.P + 31) / 32 + 2) * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->a2, nseg * c->a2_stride * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->sbv, (cf.cols * 128 / 32 + 2) * 4));
-    SOT_TRY(dev_alloc(c, (void **)&c->a_hi, ((g.tail + 31) / 32 + 1) * 4));
+    SOT_TRY(dev_alloc(c, (void **)&c->a_hi, nseg * c->ahi_stride * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->TW, TW_TABLES * 256 * 32 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->TWC, TW_TABLES * 256 * 4));
     hipLaunchKernelGGL(k_build_tw, dim3(TW_TABLES * 256 * 32 / 256), dim3(256), 0, c->stream, c->TW, c->TWC);
@@ -2792,7 +2812,8 @@ int qc_init(sot_ctx *c) {
         plan->sub_fwd.list = c->up_list + nf + ni;
         plan->sub_inv.list = c->up_list + nf + ni + sf;
     }
-    return upload_a_and_transform(c);
+    for (uint32_t sidx = 1; sidx < cf.scaler; sidx++) SOT_TRY(upload_a_and_transform(c, sidx));
+    return SOT_OK;
 }
 
 // A sharded context of 4 or more ranks holds at most 64 bit rows (2 x 128 / world, both roles): the QC kernels then skip
@@ -2836,28 +2857,42 @@ static int qc_encode_core(sot_ctx *c, const blk_t *V, const uint32_t *sb, uint32
         return SOT_EINVAL;
     }
     const bool full = c->rows_active == ROWS && out_words == 4;
-    if (full)
-        SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<true>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
-                   g.nw / 2, c->Z0, c->rows_active, out_words);
-    else
-        SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<false>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), V, sb, sbpos, nb128, cf.P, g.lo_bits,
-                   g.nw / 2, c->Z0, c->rows_active, out_words);
-    uint32_t *zb[2] = {c->Z0, c->Z1};
-    int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
-    fft_forward_upper(c, zb[cur], plan);
-    if (c->prof) prof_begin(c, KID_FFT_LOW_MUL);
-    launch_low<1>(c, zb[cur], plan.low);
-    if (c->prof) prof_end(c, KID_FFT_LOW_MUL);
-    fft_inverse_upper(c, zb[cur], plan);
-    cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
-    if (c->prof) prof_begin(c, KID_QC_FINAL);
-    if (full)
-        hipLaunchKernelGGL(k_qc_finish<true>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                           g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
-    else
-        hipLaunchKernelGGL(k_qc_finish<false>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
-                           g.nw, V, sb, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, c->a2, c->a_hi, out, c->rows_active, out_words);
-    if (c->prof) prof_end(c, KID_QC_FINAL);
+    // c = b0 + sum_{s = 1}^{scaler - 1} a_s b_s (MultAddReducer::reduce, quasi_cyclic_encode.rs:262-286), one product per pass:
+    // the pass for s sees the leaves re-based by (s - 1) nb128 Blocks, so that b_s is its "V1"; the first pass adds the b0
+    // terms and writes `out`, the later ones (scaler > 2) XOR their product into it -- the transform is linear, so summing
+    // after the inverse transforms equals the reference's sum in the transform domain.
+    for (uint32_t sidx = 1; sidx < cf.scaler; sidx++) {
+        const blk_t *Vs = (const blk_t *)((const uint32_t *)V + (uint64_t)(sidx - 1) * nb128 * out_words);
+        const uint32_t *sbs = sb ? sb + (uint64_t)(sidx - 1) * nb128 / 32 : nullptr;
+        const blk_t *V0 = sidx == 1 ? V : nullptr;
+        c->Amat_cur = c->Amat + (uint64_t)(sidx - 1) * c->amat_stride;
+        if (full)
+            SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<true>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), Vs, sbs, sbpos, nb128, cf.P, g.lo_bits,
+                       g.nw / 2, c->Z0, c->rows_active, out_words);
+        else
+            SOT_LAUNCH(c, KID_QC_LOAD, k_qc_load<false>, dim3(gridn(g.nw / 2, LD_W)), dim3(LD_T), Vs, sbs, sbpos, nb128, cf.P, g.lo_bits,
+                       g.nw / 2, c->Z0, c->rows_active, out_words);
+        uint32_t *zb[2] = {c->Z0, c->Z1};
+        int cur = run_conversion(c, zb, 0, g.m - 1, false, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
+        fft_forward_upper(c, zb[cur], plan);
+        if (c->prof) prof_begin(c, KID_FFT_LOW_MUL);
+        launch_low<1>(c, zb[cur], plan.low);
+        if (c->prof) prof_end(c, KID_FFT_LOW_MUL);
+        fft_inverse_upper(c, zb[cur], plan);
+        cur = run_conversion(c, zb, cur, g.m, true, plan.units_in_top, &plan.sub_fwd, &plan.sub_inv);
+        const uint32_t *a2s = c->a2 + (uint64_t)(sidx - 1) * c->a2_stride, *ahis = c->a_hi + (uint64_t)(sidx - 1) * c->ahi_stride;
+        if (c->prof) prof_begin(c, KID_QC_FINAL);
+        if (full)
+            hipLaunchKernelGGL(k_qc_finish<true>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
+                               g.nw, Vs, sbs, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, a2s, ahis, out, c->rows_active,
+                               out_words, V0, sb);
+        else
+            hipLaunchKernelGGL(k_qc_finish<false>, dim3(gridn(cf.n, FN_K)), dim3(256), fn_dyn_lds((uint32_t)g.tail), c->stream, zb[cur],
+                               g.nw, Vs, sbs, sbpos, nb128, cf.P, g.S, (uint32_t)g.tail, cf.n, a2s, ahis, out, c->rows_active,
+                               out_words, V0, sb);
+        if (c->prof) prof_end(c, KID_QC_FINAL);
+    }
+    c->Amat_cur = c->Amat;
     SOT_HIP(hipGetLastError());
     return SOT_OK;
 }
@@ -2875,16 +2910,16 @@ int qc_encode(sot_ctx *c, int role, const uint64_t *points, uint64_t npoints, in
         }
         std::vector<uint64_t> e(npoints);
         for (uint64_t i = 0; i < npoints; i++) {
-            const uint64_t S = points[i];
-            if (S < nb128)
+            const uint64_t S = points[i], seg = S / nb128;
+            if (seg == 0)
                 e[i] = (S % cf.P) | (1ull << 63);
-            else if (S < 2 * nb128)
-                e[i] = (S - nb128) % cf.P;
+            else if (seg < cf.scaler)
+                e[i] = ((S - seg * nb128) % cf.P) | ((seg - 1) << 56);
             else
                 e[i] = SC_DROPPED;
         }
         SOT_HIP(hipMemcpyAsync(c->d_points, e.data(), npoints * 8, hipMemcpyHostToDevice, c->stream));
-        SOT_LAUNCH(c, KID_CLEAR_LSB, k_sparse_choice, dim3(gridn((cf.n + 31) / 32, 256)), dim3(256), c->a2, cf.P, c->d_points,
+        SOT_LAUNCH(c, KID_CLEAR_LSB, k_sparse_choice, dim3(gridn((cf.n + 31) / 32, 256)), dim3(256), c->a2, c->a2_stride, cf.P, c->d_points,
                    (uint32_t)npoints, cf.n, (uint8_t *)c->d_tmp);
         SOT_HIP(hipGetLastError());
         SOT_HIP(hipMemcpyAsync(C_out, c->d_tmp, cf.n, hipMemcpyDeviceToHost, c->stream));

@@ -163,10 +163,12 @@ struct sot_ctx {
     uint32_t *MT1 = nullptr, *MT2 = nullptr; // twiddle masks of the 16-plane passes (levels 9..12 / 13..16)
     void *qc_plan = nullptr;                // fft_plan (qc.hip): tile descriptors of the passes
     uint32_t *up_list = nullptr;            // move lists of the whole-unit conversion phases
-    uint32_t *Amat = nullptr;               // per value word multiply-by-FFT(a) bit matrices [nw/32][432] (packed)
-    uint32_t *a2 = nullptr;                 // a mod (x^P - 1), bit vector repeated twice (words)
-    uint32_t *a_hi = nullptr;               // tail bits of a (host copy in a_hi_host)
-    std::vector<uint32_t> a_hi_host;
+    // the public polynomials a_s, s = 1 .. scaler - 1 (quasi_cyclic_encode.rs:127-138), one block of each table per s
+    uint32_t *Amat = nullptr;               // [s-1][nw/32][432] per value word multiply-by-FFT(a_s) bit matrices (packed)
+    uint32_t *Amat_cur = nullptr;           // the block the low kernel multiplies by (qc_encode_core sets it per pass)
+    uint32_t *a2 = nullptr;                 // [s-1][a2_stride] a_s mod (x^P - 1) as a bit vector (+ 2 padding words)
+    uint32_t *a_hi = nullptr;               // [s-1][ahi_stride] tail bits a_s'[S .. P)
+    uint64_t amat_stride = 0, a2_stride = 0, ahi_stride = 0;  // words
     uint64_t *d_points = nullptr;
     uint32_t *sbv = nullptr;  // receiver noise indicator: one bit per Block of V (silent_ot/mod.rs:560-574)
     // MT bits

@@ -45,7 +45,7 @@ extern "C" {
 /* QuasiCyclicConf (zappot/src/silent_ot/quasi_cyclic_encode.rs:156-233) + PprfConfig (pprf.rs:40-44) */
 typedef struct sot_conf {
     uint64_t n;        /* requested_num_ots */
-    uint64_t scaler;   /* MultType::QuasiCyclic{scaler}; only 2 is supported (bench.rs:85) */
+    uint64_t scaler;   /* MultType::QuasiCyclic{scaler}: 2 (what bench.rs:85 uses) .. 8; scaler - 1 public polynomials a_s */
     uint64_t P;        /* next_prime(max(n, 128*128)) */
     uint64_t parts;    /* num_partitions = GGM trees */
     uint64_t size_per; /* PPRF domain */
@@ -70,7 +70,8 @@ int sot_configure(uint64_t n, uint64_t scaler, uint64_t sec_param, sot_conf *out
 
 /* Encoder::configure + pprf::{Sender,Receiver}::new + init_a_polynomials
  * (silent_ot/mod.rs:148,331; quasi_cyclic_encode.rs:127-138): allocates every device buffer for one
- * sender and one receiver instance of `n` OTs and transforms the public polynomial a once. */
+ * sender and one receiver instance of `n` OTs and transforms the scaler - 1 public polynomials a_s once. A geometry with
+ * n_blocks * 128 < P (possible for scaler > 2 at some n; the reference's modp panics on it) is refused with SOT_EINVAL. */
 int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx **out);
 void sot_ctx_destroy(sot_ctx *ctx);
 int sot_ctx_conf(const sot_ctx *ctx, sot_conf *out);

@@ -705,16 +705,17 @@ void orc_modp(orc_block *dest, uint64_t dest_len, const orc_block *inp, uint64_t
     if (rem) memset(db + p_bytes, 0, rem);
 }
 
-/* quasi_cyclic_encode.rs:127-138, scaler 2 only: AesRng::from_seed(Block::from(1)) */
-void orc_qc_a_poly(const orc_conf *c, uint64_t *a_out) {
+/* quasi_cyclic_encode.rs:127-138: a_s = the first n64 u64 of AesRng::from_seed(Block::from(s)), s = 1 .. scaler - 1 */
+void orc_qc_a_poly_s(const orc_conf *c, uint64_t sidx, uint64_t *a_out) {
     uint8_t seed[16];
-    u128_key(1, 0, seed);
+    u128_key(sidx, 0, seed);
     uint64_t nblk = (c->n64 + 1) / 2;
     uint8_t *tmp = (uint8_t *)malloc(nblk * 16);
     orc_aes_rng_blocks(seed, 0, tmp, nblk);
     memcpy(a_out, tmp, c->n64 * 8);
     free(tmp);
 }
+void orc_qc_a_poly(const orc_conf *c, uint64_t *a_out) { orc_qc_a_poly_s(c, 1, a_out); }
 
 /* per calling thread: two host threads run the two directions concurrently (bench.py cpu_baseline) */
 static __thread orc_block *g_cmodp = NULL;
@@ -725,12 +726,22 @@ const orc_block *orc_last_cmodp(uint64_t *rows, uint64_t *cols) {
     return g_cmodp;
 }
 
-/* quasi_cyclic_encode.rs:262-286 (scaler == 2) */
+/* quasi_cyclic_encode.rs:262-286. a: the scaler - 1 public polynomials, n64 words each; the reference sums the products in
+ * the transform domain (c_poly.add_eq), which equals the XOR of the products */
 static void qc_reduce(const orc_conf *c, const uint64_t *a, orc_block *dest, const orc_block *b128) {
     uint64_t n64 = c->n64, nb = c->n_blocks;
-    const uint64_t *b64 = (const uint64_t *)b128 + n64; /* [s*n64 .. (s+1)*n64), s = 1 */
-    orc_block *temp = (orc_block *)malloc(2 * nb * sizeof(orc_block));
-    orc_gf2x_mul((uint64_t *)temp, a, b64, n64);
+    orc_block *temp = (orc_block *)calloc(2 * nb, sizeof(orc_block));
+    orc_block *prod = c->scaler > 2 ? (orc_block *)malloc(2 * nb * sizeof(orc_block)) : NULL;
+    for (uint64_t s = 1; s < c->scaler; s++) {
+        const uint64_t *b64 = (const uint64_t *)b128 + s * n64; /* [s*n64 .. (s+1)*n64) */
+        if (s == 1) {
+            orc_gf2x_mul((uint64_t *)temp, a, b64, n64);
+        } else {
+            orc_gf2x_mul((uint64_t *)prod, a + (s - 1) * n64, b64, n64);
+            for (uint64_t i = 0; i < 2 * nb; i++) temp[i] = bxor(temp[i], prod[i]);
+        }
+    }
+    free(prod);
     for (uint64_t i = 0; i < nb; i++) temp[i] = bxor(temp[i], b128[i]);
     orc_modp(dest, nb, temp, 2 * nb, c->P);
     free(temp);
@@ -748,10 +759,13 @@ static void qc_copy_out(orc_block *dest, uint64_t num_blocks, const orc_block *c
 
 static int qc_encode_common(const orc_conf *c, const orc_block *rT, const orc_block *sb, int packed, orc_block *out,
                             uint8_t *out_C) {
-    if (c->scaler != 2) return -1;
+    if (c->scaler < 2) return -1;
+    /* the reference's modp copies ceil(P / 8) bytes into a dest of n_blocks Blocks (quasi_cyclic_encode.rs:289-303): a geometry
+     * with n_blocks * 128 < P panics there; refuse it here */
+    if (c->n_blocks * 128 < c->P) return -2;
     uint64_t nb = c->n_blocks;
-    uint64_t *a = (uint64_t *)malloc(c->n64 * 8);
-    orc_qc_a_poly(c, a);
+    uint64_t *a = (uint64_t *)malloc((c->scaler - 1) * c->n64 * 8);
+    for (uint64_t s = 1; s < c->scaler; s++) orc_qc_a_poly_s(c, s, a + (s - 1) * c->n64);
     free(g_cmodp);
     g_cmodp = (orc_block *)calloc(128 * nb, sizeof(orc_block));
     g_cmodp_rows = 128;

@@ -105,6 +105,7 @@ void orc_bit_shift_xor(orc_block *dest, uint64_t dest_len, const orc_block *inp,
 void orc_modp(orc_block *dest, uint64_t dest_len, const orc_block *inp, uint64_t inp_len, uint64_t p);
 /* quasi_cyclic_encode.rs:127-138: a_s for s=1 (scaler 2): n64 u64 of AesRng(seed=Block(1)) */
 void orc_qc_a_poly(const orc_conf *c, uint64_t *a_out);
+void orc_qc_a_poly_s(const orc_conf *c, uint64_t sidx, uint64_t *a_out);
 /* quasi_cyclic_encode.rs:29-52. rT 128 x cols. out_B has n Blocks. */
 int orc_qc_dual_encode(const orc_conf *c, const orc_block *rT, orc_block *out_B);
 /* quasi_cyclic_encode.rs:54-124 + mod.rs:552-575. S = points (parts entries).

@@ -404,3 +404,49 @@ def test_receiver_unpacked_choice_bits(fa, orc, n, T, seed):
         eng.receiver_hash()  # allowed again
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("scaler,n,T", [(3, 40000, 3), (3, 1 << 16, 4), (4, 1000, 2), (4, 100003, 5), (3, 1 << 20, 4)])
+def test_other_scalers_match_oracle(fa, orc, scaler, n, T):
+    """MultType::QuasiCyclic{scaler} for scaler 3 and 4 (quasi_cyclic_encode.rs:127-138: scaler - 1 public polynomials a_s
+    from AesRng(Block::from(s)); :262-286: c = b0 + sum_s a_s b_s): the whole pipeline of both roles -- TreeGrps, rT, B, A,
+    hashes, MT words, and the unpacked choice vector (points in segment s contribute shifts of a_s') -- bit for bit against
+    the oracle, at sizes whose geometry the reference accepts (n_blocks * 128 >= P; its modp panics otherwise)."""
+    conf = orc.configure(n, scaler=scaler)
+    assert conf.n_blocks * 128 >= conf.P
+    rng = np.random.default_rng(100 * scaler + T)
+    msg2, msg, choices = orc.fake_base(conf, rng)
+    delta = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    prg = rng.integers(0, 2 ** 64, 2, dtype=np.uint64)
+    o_rT, o_sums, o_last = orc.pprf_sender_expand(conf, msg2, delta, prg, T)
+    o_B = orc.qc_dual_encode(conf, o_rT)
+    o_rTr = orc.pprf_receiver_expand(conf, msg, choices, o_sums, o_last)
+    pts = orc.pprf_points(conf, choices)
+    o_A, _ = orc.qc_dual_encode2(conf, o_rTr, pts, packed=True)
+    o_Au, o_C = orc.qc_dual_encode2(conf, o_rTr, pts, packed=False)
+    eng = fa.Engine(n, mult_type=fa.MultType(scaler))
+    try:
+        assert eng.conf.c.as_dict() == conf.as_dict()
+        sums, last = eng.sender_expand(msg2, delta, prg, T)
+        assert np.array_equal(sums, o_sums) and np.array_equal(last, o_last)
+        assert np.array_equal(eng.download_rT(0), o_rT)
+        eng.qc_encode(0)
+        assert np.array_equal(eng.download_encoded(0), o_B), "sender B"
+        eng.receiver_expand(msg, choices, sums, last)
+        assert np.array_equal(eng.points(choices), pts)
+        assert np.array_equal(eng.download_rT(1), o_rTr)
+        eng.qc_encode(1, pts)
+        assert np.array_equal(eng.download_encoded(1), o_A), "receiver A (packed)"
+        s_msgs = eng.sender_hash(delta)
+        r_msgs, ch = eng.receiver_hash()
+        o_s = orc.sender_hash(delta, o_B)
+        o_r, o_ch = orc.receiver_hash(o_A)
+        assert np.array_equal(s_msgs, o_s.reshape(s_msgs.shape)) and np.array_equal(r_msgs, o_r) and np.array_equal(ch, o_ch)
+        a, b, c = eng.mt_bits(delta)
+        oa, ob, oc = orc.mt_bits(o_s.reshape(-1, 2), o_r, o_ch)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob) and np.array_equal(c, oc)
+        Cv = eng.qc_encode2(pts, packed=False)
+        assert np.array_equal(eng.download_encoded(1), o_Au), "receiver A (unpacked)"
+        assert np.array_equal(Cv, np.asarray(o_C, dtype=np.uint8).reshape(-1)[:n]), "choice vector C"
+    finally:
+        eng.close()

@@ -39,9 +39,9 @@ def _local_exchange(pipes):
     return make, flush
 
 
-def _run_sharded(fa, n, T, world, replicated, x, y, tg_y, delta, seed):
+def _run_sharded(fa, n, T, world, replicated, x, y, tg_y, delta, seed, scaler=2):
     from flute_amd import dist as fd
-    engs = [fa.ShardedEngine(n, r, world, ggm_replicated=replicated) for r in range(world)]
+    engs = [fa.ShardedEngine(n, r, world, ggm_replicated=replicated, mult_type=fa.MultType(scaler)) for r in range(world)]
     try:
         pipes = [None] * world
         make, flush = _local_exchange(pipes)
@@ -105,10 +105,16 @@ CASES = [(1000, 2, 2, False), (1000, 2, 4, False), (1000, 2, 8, False), (1000, 1
          (1 << 24, 4, 2, True), (1 << 24, 4, 8, False), (1 << 26, 4, 4, False), (1 << 26, 4, 8, False)]
 
 
+@pytest.mark.parametrize("n,T,world,replicated,scaler", [(40000, 3, 4, False, 3), (100003, 2, 8, False, 4), (65536, 2, 2, True, 3)])
+def test_sharded_expansion_other_scalers(fa, n, T, world, replicated, scaler):
+    """MultType::QuasiCyclic{scaler: 3 / 4} sharded: one product pass per public polynomial a_s over the slot Blocks"""
+    test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated, scaler)
+
+
 @pytest.mark.parametrize("n,T,world,replicated", CASES)
-def test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated):
+def test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated, scaler=2):
     rng = np.random.default_rng(n % 1009 + world)
-    ref = fa.Engine(n)
+    ref = fa.Engine(n, mult_type=fa.MultType(scaler))
     try:
         conf = ref.conf
         x = fa.fake_base(conf, rng)  # direction X: this party sends
@@ -125,7 +131,7 @@ def test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated):
         w_mt = np.stack(ref.mt_bits(delta))
     finally:
         ref.close()
-    sums, last, B, A, sm, rm, ch, mt = _run_sharded(fa, n, T, world, replicated, x, y, tg_y, delta, seed)
+    sums, last, B, A, sm, rm, ch, mt = _run_sharded(fa, n, T, world, replicated, x, y, tg_y, delta, seed, scaler)
     assert np.array_equal(sums, w_sums) and np.array_equal(last, w_last), "TreeGrps"
     assert np.array_equal(B, w_B), "sender B"
     assert np.array_equal(A, w_A), "receiver A"
