@@ -337,9 +337,26 @@ def load_pmc():
     the profiler on itself; tools/profile.sh + tools/prof_summary.py produce profiles/pmc_latest.json)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return json.load(f)
+            pmc = json.load(f)
     except (OSError, ValueError):
         return None
+    # the counters describe the kernels of the commit they were collected on: compare the source hashes stamped into the
+    # file (tools/prof_summary.py) with the sources of this tree, and report nothing counter-derived when they differ
+    import hashlib
+    stale = []
+    for fn, want in (pmc.get("source_sha256") or {"qc.hip": None}).items():
+        try:
+            with open(os.path.join(ROOT, "flute_amd", "csrc", fn), "rb") as fh:
+                got = hashlib.sha256(fh.read()).hexdigest()
+        except OSError:
+            got = None
+        if got != want:
+            stale.append(fn)
+    if stale:
+        return {"stale": True, "note": "profiles/pmc_latest.json (commit %s) was collected on other versions of %s: the "
+                                       "counter-derived fields are omitted" % (pmc.get("source_commit"), ", ".join(stale))}
+    pmc["note"] = "%s; counters collected at commit %s (source hashes match this tree)" % (pmc.get("note"), pmc.get("source_commit"))
+    return pmc
 
 
 def roles_main(args, fa, fd, dist, torch, rank, local_rank, world, n):
@@ -590,6 +607,8 @@ def main():
     ap.add_argument("--split", choices=("auto", "rows", "roles"), default="auto",
                     help="strong mode: rows = bit rows of both roles sharded over the ranks (2, 4, 8 ranks), roles = one "
                          "direction per GPU (2 ranks; auto picks it there: nothing of the expansion crosses the link)")
+    ap.add_argument("--sync-stages", action="store_true",
+                    help="one GPU: every stage call waits for the GPU before it returns (round 2's behaviour)")
     ap.add_argument("--no-ordered", action="store_true",
                     help="strong mode: every stage call waits for the GPU (round 2's behaviour) instead of the stream-ordered pipeline")
     ap.add_argument("--no-overlap", action="store_true",
@@ -657,6 +676,10 @@ def main():
         torch.cuda.synchronize()
         fd.barrier(world)
 
+    # stream-ordered context (sot_ctx_set_async): the stage calls that return nothing to the host do not wait for the GPU, so
+    # the launches of a stage are queued while the previous stage still runs; the step's one host wait is the TreeGrp
+    # download of the sender's expansion (the payload the peer party needs), the timed region ends with a full sync
+    eng.set_async(not args.sync_stages)
     for _ in range(args.warmup):
         step()
     # timed region: EXACTLY args.steps steps, no per-kernel events (bracketing all ~110 launches of a step with HIP
@@ -683,6 +706,7 @@ def main():
         dt_prof = time.perf_counter() - t1
         eng.prof_enable(False)
         prof = eng.prof_read()
+    eng.set_async(False)
 
     # size-independent correctness property on the last step (check_correlated, silent_ot/mod.rs:744-777
     # cannot be used here because X and Y are different OT instances; the MT relation needs the peer).
@@ -741,6 +765,9 @@ def main():
                 st["frac"] = st["achieved"] / st["peak"] if st["achieved"] else None
             out["stages"] = stages
             pmc = load_pmc()
+            if pmc and pmc.get("stale"):
+                out["roofline"]["traffic_note"] = pmc["note"]
+                pmc = None
             if pmc:
                 out["roofline"]["traffic"] = pmc.get("dominant_traffic_bytes_per_launch")
                 out["roofline"]["traffic_note"] = pmc.get("note")

@@ -120,6 +120,19 @@ def main():
                 # per second of GGM kernel time, summed over the stage's launches of the profiled run
                 out["ggm_valu_insts_per_s"] = g["valu"] / (g["ns"] * 1e-9)
                 out["ggm_lds_insts_per_s"] = g["lds"] / (g["ns"] * 1e-9)
+        # what the counters were collected on: bench.py compares these hashes with the sources it runs and drops the
+        # counter-derived fields when a kernel file has changed since (the numbers would describe other kernels)
+        import hashlib
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out["source_sha256"] = {}
+        for fn in ("qc.hip", "ggm.hip", "aes_dev.h"):
+            with open(os.path.join(root, "flute_amd", "csrc", fn), "rb") as fh:
+                out["source_sha256"][fn] = hashlib.sha256(fh.read()).hexdigest()
+        try:
+            out["source_commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            out["source_commit"] = None
         with open(os.path.join(os.path.dirname(prefix), "pmc_latest.json"), "w") as f:
             json.dump(out, f, indent=1)
 

@@ -31,7 +31,7 @@ def main():
         delta, seed, delta_peer, seed_peer = (rng.integers(0, 2 ** 64, 2, dtype=np.uint64) for _ in range(4))
         tg_y = eng.sender_expand(y[0], delta_peer, seed_peer, 4)
         pts = eng.points(y[2])
-        pipe = fd.ShardedPipeline(eng, exchange=lambda s, r: None)
+        pipe = fd.ShardedPipeline(eng, exchange=lambda s, r: None, ordered=True, overlap=True)  # as bench.py runs it
 
         def step():
             pipe.expand(x[0], delta, seed, 4, y[1], y[2], *tg_y)
@@ -40,25 +40,26 @@ def main():
             pipe.mt_bits(delta, gather=False)
 
         step()
-        eng.sync()
+        pipe.sync()
         torch.cuda.synchronize()
         reps = 5
         t0 = time.perf_counter()
         for _ in range(reps):
             step()
-        eng.sync()
+        pipe.sync()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
         eng.prof_reset()
         eng.prof_enable(True)
         step()
-        eng.sync()
+        pipe.sync()
         eng.prof_enable(False)
         prof = {k: round(v[0], 3) for k, v in sorted(eng.prof_read().items(), key=lambda kv: -kv[1][0]) if v[0] > 0.05}
         out["ranks"].append({"world": world, "ggm": "replicated" if repl else "sharded", "compute_ms_per_step": round(ms, 3),
                              "rows_per_rank_and_role": 128 // world,
                              "exchange1_bytes_to_each_peer": eng.x1_bytes, "exchange2_bytes_to_each_peer": eng.x2_bytes,
                              "kernels_ms": prof})
+        pipe.close()
         eng.close()
         del pipe
         torch.cuda.empty_cache()
