@@ -513,8 +513,20 @@ static int launch_levels(sot_ctx *c, bool receiver, blk_t *V) {
         // the leaf level has enough work per workgroup and balances better with many. A shard with fewer sets takes
         // proportionally more workgroups per set.
         unsigned cap = d + 1 < depth ? 64 : 256;
-        if (nl < nsets) cap = cap * nsets / nl;
+        if (nl < nsets) {
+            // ... rounded up to a power of two: the grid stride must divide the level for the kernel's four-chain path
+            // (per_set % (2 * stride) == 0); 64 * 15 / 2 = 480 workgroups sent every level of an 8-rank shard down the
+            // two-chain path
+            unsigned want = cap * (unsigned)nsets / nl, p2 = cap;
+            while (p2 < want) p2 <<= 1;
+            cap = p2;
+        }
         unsigned gx = grid_for(per_set, GGM_BLOCK, cap);
+        // a shard's level holds nl / nsets of the work: with the workgroup count of a whole level each workgroup would fill
+        // its 64 KiB AES table for one or two parents per thread. Halve the grid while more than two workgroups per CU
+        // would each see fewer than 16 parents per thread.
+        if (nl < nsets)
+            while (gx > 1 && (uint64_t)gx * nl > 2 * c->num_cus && per_set / ((uint64_t)gx * GGM_BLOCK) < 16) gx >>= 1;
         dim3 grid(gx, nl);
         blk_t *lsum = c->sums + (uint64_t)d * nsets * 16;
         if (d + 1 < depth) {
