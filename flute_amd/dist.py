@@ -261,20 +261,26 @@ class ShardedPipeline:
             else:
                 self.mt.zero_()
             out = gather_sharded_words(self.mt, self.world) if gather else self.mt
-        self._hand_over()
+        self._hand_over(out)
         return out
 
-    def _hand_over(self):
-        """results made on the pipeline's stream are about to be used on the caller's: a stream-side wait, no host sync"""
+    def _hand_over(self, *tensors):
+        """results made on the pipeline's stream are about to be used on the caller's: a stream-side wait, no host sync;
+        `tensors` came from the caching allocator under the pipeline's stream and must not be recycled there while the
+        caller's stream still reads them"""
         if self.ordered:
             import torch
-            torch.cuda.current_stream(self.mt.device).wait_stream(self.stream)
+            cur = torch.cuda.current_stream(self.mt.device)
+            cur.wait_stream(self.stream)
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
 
     def gather_blocks(self, what, delta=None, buf=None):
         """gather_sharded_blocks on this pipeline's stream: the whole B / A / hashed-message vector on every rank"""
         with self._on_stream():
             out = gather_sharded_blocks(self.eng, what, self.world, delta=delta, buf=buf)
-        self._hand_over()
+        self._hand_over(*out)
         return out
 
     def sync(self):
