@@ -21,51 +21,69 @@
 #include "sot_internal.h"
 
 #define AZ_THREADS 1024
-#define AZ_TILES (AZ_THREADS / 128)
+#define AZ_TILES (AZ_THREADS / 64)  // one wavefront per 128-OT tile
+#ifndef AZ_GRID
+#define AZ_GRID 256  // workgroups: one per CU (112 KiB of LDS each), every one fills its tables once
+#endif
 
+// words per row of the per-lane round keys in LDS: 44 (sender: one key per base OT) or 2 x 44 + 4 (receiver: the pad makes
+// the row stride an odd number of 16-byte pieces, so the ds_read_b128 of 8 consecutive lanes fall into different banks)
+#define AZ_KSTRIDE(SENDER) ((SENDER) ? 44 : 92)
+
+// A wavefront owns a whole tile (column j of the 128 x nj Block matrix): lane l computes rows l and l + 64 -- two
+// (sender) or four (receiver) independent AES chains per lane --, the 128 x 128 bit transpose stays in the wave's
+// registers (bm_transpose128_wave) and the lane hashes OTs 128 j + l and 128 j + l + 64. No barrier inside the loop: the
+// sixteen waves of the workgroup drift apart and overlap each other's lookup, transpose and store phases.
 template <bool SENDER>
 __global__ void __launch_bounds__(AZ_THREADS)
     k_alsz(const uint32_t *__restrict__ rks /* SENDER: [128][44], else [128][2][44] */, const blk_t *__restrict__ choices,
            blk_t delta, const uint8_t *__restrict__ base_choice /* SENDER: [128] 0/1 */, blk_t *__restrict__ U /* [128][nj] */,
            uint64_t nj, uint64_t count, blk_t *__restrict__ out) {
+    constexpr uint32_t KW = SENDER ? 44 : 88, KS = AZ_KSTRIDE(SENDER);
     __shared__ uint32_t te[1][AES_LDS_WORDS];
-    __shared__ uint32_t keys[128 * (SENDER ? 1 : 2) * 44];
-    __shared__ uint32_t xch[AZ_TILES][512];  // word exchange of the tile transposes (bitmat_dev.h)
+    __shared__ __align__(16) uint32_t keys[128 * KS];
     aes_lds_fill(te);
-    for (uint32_t i = threadIdx.x; i < 128 * (SENDER ? 1 : 2) * 44; i += AZ_THREADS) keys[i] = rks[i];
+    for (uint32_t i = threadIdx.x; i < 128 * KW; i += AZ_THREADS) keys[(i / KW) * KS + i % KW] = rks[i];
     __syncthreads();
-    const uint32_t r = threadIdx.x & 127, tl = threadIdx.x >> 7;
-    const uint32_t *k0 = keys + r * (SENDER ? 44 : 88);
-    const uint32_t rbit = SENDER ? base_choice[r] : 0;
-    for (uint64_t j0 = (uint64_t)blockIdx.x * AZ_TILES; j0 < nj; j0 += (uint64_t)gridDim.x * AZ_TILES) {
-        const uint64_t j = j0 + tl;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (j < nj) {
-            const blk_t ctr = make_uint4((uint32_t)j, (uint32_t)(j >> 32), 0, 0);
-            blk_t t = aes_encrypt<true>(te, k0, ctr);
-            if (SENDER) {
-                if (rbit) t = bxor(t, U[(uint64_t)r * nj + j]);  // v ^= r_j * u_j (:118-126)
-            } else {
-                const blk_t u = bxor(bxor(aes_encrypt<true>(te, k0 + 44, ctr), t), choices[j]);  // :212-217
-                U[(uint64_t)r * nj + j] = u;
-            }
-            w[0] = t.x, w[1] = t.y, w[2] = t.z, w[3] = t.w;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *ka = keys + lane * KS, *kb = keys + (lane + 64) * KS;
+    const uint32_t rbit_a = SENDER ? base_choice[lane] : 0, rbit_b = SENDER ? base_choice[lane + 64] : 0;
+    blk_t *Ua = U + (uint64_t)lane * nj, *Ub = U + (uint64_t)(lane + 64) * nj;
+    for (uint64_t j = (uint64_t)blockIdx.x * AZ_TILES + wave; j < nj; j += (uint64_t)gridDim.x * AZ_TILES) {
+        const blk_t ctr = make_uint4((uint32_t)j, (uint32_t)(j >> 32), 0, 0);
+        blk_t ta, tb;
+        // receiver: rows l and l + 64 one after the other (four chains at once keep four sets of per-lane round keys in
+        // flight: 128 VGPRs + 560 B of scratch per lane)
+        if (SENDER) {
+            const blk_t ua = Ua[j], ub = Ub[j];
+            ta = aes_encrypt<true>(te, ka, ctr);
+            tb = aes_encrypt<true>(te, kb, ctr);
+            if (rbit_a) ta = bxor(ta, ua);  // v ^= r_j * u_j (:118-126)
+            if (rbit_b) tb = bxor(tb, ub);
+        } else {
+            const blk_t ch = choices[j];
+            ta = aes_encrypt<true>(te, ka, ctr);
+            Ua[j] = bxor(bxor(aes_encrypt<true>(te, ka + 44, ctr), ta), ch);  // :212-217
+            __builtin_amdgcn_sched_barrier(0);
+            tb = aes_encrypt<true>(te, kb, ctr);
+            Ub[j] = bxor(bxor(aes_encrypt<true>(te, kb + 44, ctr), tb), ch);
         }
+        __builtin_amdgcn_sched_barrier(0);
         // OT i = 128 j + r: bit q of its Block = bit r of row q -- the 128 x 128 bit transpose of the tile, in registers
-        bm_transpose128(w, xch[tl], r);
-        if (j < nj) {
-            const uint64_t i = 128 * j + r;
-            if (i < count) {
-                const blk_t x = make_uint4(w[0], w[1], w[2], w[3]);
-                if (SENDER) {
-                    out[2 * i] = cr_hash(te, x);
-                    out[2 * i + 1] = cr_hash(te, bxor(x, delta));
-                } else {
-                    out[i] = cr_hash(te, x);
-                }
-            }
+        uint32_t w[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+        bm_transpose128_wave(w, lane);
+        const uint64_t ia = 128 * j + lane, ib = ia + 64;
+        const blk_t xa = make_uint4(w[0], w[1], w[2], w[3]), xb = make_uint4(w[4], w[5], w[6], w[7]);
+        if (SENDER) {
+            const blk_t a0 = cr_hash(te, xa), a1 = cr_hash(te, bxor(xa, delta));
+            const blk_t b0 = cr_hash(te, xb), b1 = cr_hash(te, bxor(xb, delta));
+            if (ia < count) out[2 * ia] = a0, out[2 * ia + 1] = a1;
+            if (ib < count) out[2 * ib] = b0, out[2 * ib + 1] = b1;
+        } else {
+            const blk_t a0 = cr_hash(te, xa), b0 = cr_hash(te, xb);
+            if (ia < count) out[ia] = a0;
+            if (ib < count) out[ib] = b0;
         }
-        __syncthreads();
     }
 }
 
@@ -191,7 +209,7 @@ static int alsz_keys(sot_alsz_ctx *a, const void *base_ots, uint32_t nkeys) {
 }
 static inline unsigned alsz_grid(uint64_t nj) {
     uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
-    return (unsigned)(g > 512 ? 512 : g);
+    return (unsigned)(g > AZ_GRID ? AZ_GRID : g);
 }
 
 // Receiver::receive (ot_ext/mod.rs:156-237). choice_bytes: count / 8 bytes, host memory or (choices_on_device != 0)
@@ -359,7 +377,7 @@ extern "C" int sot_alsz_receive_noalloc(int device, const void *base_ots, const 
     SOT_HIP(hipMemset(d_ch, 0, nj * 16));
     SOT_HIP(hipMemcpy(d_ch, choice_bytes, cols, hipMemcpyHostToDevice));
     uint64_t g = (nj + AZ_TILES - 1) / AZ_TILES;
-    if (g > 512) g = 512;
+    if (g > AZ_GRID) g = AZ_GRID;
     // U[r][j] (r < 128, j < nj) and out[i] (i < count) are written in full by the kernel before they are read back
     hipLaunchKernelGGL(k_alsz<false>, dim3((unsigned)g), dim3(AZ_THREADS), 0, 0, d_rks, d_ch, make_uint4(0, 0, 0, 0),
                        (const uint8_t *)nullptr, d_U, nj, count, d_out);
