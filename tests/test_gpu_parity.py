@@ -450,3 +450,67 @@ def test_other_scalers_match_oracle(fa, orc, scaler, n, T):
         assert np.array_equal(Cv, np.asarray(o_C, dtype=np.uint8).reshape(-1)[:n]), "choice vector C"
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------ device-resident outputs, stream-ordered context
+def test_blocks_to_device_and_stream_ordered_context(fa, orc):
+    """sot_blocks_to_device hands out the same B / A / hashed messages as the host downloads; a context queued on the
+    caller's stream without per-stage waits (sot_ctx_set_stream / sot_ctx_set_async) produces the same MT words as the
+    synchronous call sequence (whose results the oracle pins in test_pipeline_stages_match_oracle)."""
+    import torch
+    n, T = 40000, 3
+    conf, msg2, msg, choices, delta, prg = _inputs(orc, n, 21)
+    eng = fa.Engine(n)
+    dev = torch.device("cuda", 0)
+    try:
+        buf = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+        with pytest.raises(fa.SotError):  # nothing encoded yet
+            eng.blocks_to_device(eng.OUT_B, buf.data_ptr(), buf.numel() * 8)
+        sums, last = eng.sender_expand(msg2, delta, prg, T)
+        eng.receiver_expand(msg, choices, sums, last)
+        pts = eng.points(choices)
+        eng.qc_encode(0)
+        eng.qc_encode(1, pts)
+        B, A = eng.download_encoded(0), eng.download_encoded(1)
+        smsgs = eng.sender_hash(delta)
+        rmsgs, _ = eng.receiver_hash()
+        want_mt = eng.mt_bits(delta)
+        for what, want, per in ((eng.OUT_B, B, 2), (eng.OUT_A, A, 2), (eng.OUT_SENDER_MSGS, smsgs, 4),
+                                (eng.OUT_RECEIVER_MSGS, rmsgs, 2)):
+            buf.fill_(-1)
+            torch.cuda.synchronize()
+            eng.blocks_to_device(what, buf.data_ptr(), buf.numel() * 8, delta=delta)
+            got = buf[:n * per].cpu().numpy().view(np.uint64).reshape(want.shape)
+            assert np.array_equal(got, want), what
+            assert (buf[n * per:] == -1).all()  # nothing written past the n outputs
+        with pytest.raises(fa.SotError):  # destination too small
+            eng.blocks_to_device(eng.OUT_SENDER_MSGS, buf.data_ptr(), n * 32 - 8, delta=delta)
+        with pytest.raises(fa.SotError):  # the sender's hash needs delta
+            eng.blocks_to_device(eng.OUT_SENDER_MSGS, buf.data_ptr(), buf.numel() * 8)
+        with pytest.raises(fa.SotError):
+            eng.blocks_to_device(7, buf.data_ptr(), buf.numel() * 8)
+        # the same step queued on a torch stream, no wait between the stages that hand nothing to the host
+        st = torch.cuda.Stream(dev)
+        nw = (n + 63) // 64
+        mt = torch.zeros(3 * nw, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        eng.set_stream(st.cuda_stream)
+        eng.set_async(True)
+        with torch.cuda.stream(st):
+            for rep in range(2):  # the second pass reuses the pinned staging ring
+                sums2, last2 = eng.sender_expand(msg2, delta, prg, T)
+                eng.receiver_expand(msg, choices, sums2, last2)
+                eng.qc_encode(0)
+                eng.qc_encode(1, pts)
+                eng.mt_bits(delta, download=False)
+                eng.mt_bits_to_device(mt.data_ptr(), mt.numel() * 8)
+        st.synchronize()
+        assert np.array_equal(sums2, sums) and np.array_equal(last2, last)
+        got = mt.cpu().numpy().view(np.uint64).reshape(3, nw)
+        assert all(np.array_equal(got[i], want_mt[i]) for i in range(3))
+        eng.set_async(False)
+        eng.set_stream(None)
+        a, b, c = eng.mt_bits(delta)  # back on its own stream, synchronous
+        assert np.array_equal(a, want_mt[0]) and np.array_equal(c, want_mt[2])
+    finally:
+        eng.close()
