@@ -606,7 +606,7 @@ __device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, 
 // overlap there is; with RQ = 2 a second workgroup on the CU overlaps its phases with this one's barriers as well).
 template <bool INV, int RQ>
 __global__ void __launch_bounds__(256 * RQ) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t nact) {
+k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t nact, uint32_t *__restrict__ ctr) {
     constexpr uint32_t T = 256 * RQ;      // threads
     constexpr uint32_t SU = 9 * RQ;       // u4 per sub-unit in LDS: 8 words x RQ quads + one word of padding
     constexpr uint32_t LANES = 8 * RQ;    // u4 of a sub-unit = lanes per move in P2
@@ -618,12 +618,17 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
         const uint32_t t = xcd_slice_order(v, nact, ntiles);
         return D + (uint64_t)(t / nact) * 2048 * ROWS + (t & (nact - 1u)) * (4 * RQ);
     };
-    uint32_t t = blockIdx.x;
+    // tiles blockIdx.x and blockIdx.x + gridDim.x, then drawn from *ctr (zero at launch) one tile ahead: see k_mid
+    __shared__ uint32_t s_next;
+    uint32_t t = blockIdx.x, tn = blockIdx.x + gridDim.x;
     if (t >= ntiles) return;
     for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += T) mvl[i] = mv.list[i];
     cu_regs nx = cu_load_tile<INV>(gptr(t), su, quad);
 #pragma unroll 1
-    for (; t < ntiles; t += gridDim.x) {
+    for (; t < ntiles; t = tn, tn = __builtin_amdgcn_readfirstlane(s_next)) {
+        uint32_t drawn = 0;
+        // (one counter per XCD residue: xcd_slice_order relies on tile v running on XCD v % 8)
+        if (threadIdx.x == 0) drawn = (gridDim.x % 8 ? atomicAdd(ctr, 1u) : atomicAdd(ctr + (blockIdx.x & 7u), 1u) * 8 + (blockIdx.x & 7u)) + 2 * gridDim.x;
         uint32_t *g = gptr(t);
         {
             u4 w[8] = {nx.a, nx.b, nx.c, nx.d, nx.e, nx.f, nx.g, nx.h};
@@ -639,7 +644,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
         __syncthreads();
         {  // next tile: in flight during the LDS phases (the last iteration re-reads its own tile: unconditional
            // loads keep w[] in registers)
-            nx = cu_load_tile<INV>(gptr(t + gridDim.x < ntiles ? t + gridDim.x : t), su, quad);
+            nx = cu_load_tile<INV>(gptr(tn < ntiles ? tn : t), su, quad);
         }
         // P2 forward comes after P1, inverse before it
         for (int part = 0; part < 2; part++) {
@@ -713,6 +718,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
 #pragma unroll
             for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(su + 256 * j) * ROWS + 4 * quad) = lds[cu_idx<RQ>(su + 256 * j) + quad];
         }
+        if (threadIdx.x == 0) s_next = drawn;
         __syncthreads();  // the tile's LDS is free again
     }
 }
@@ -1708,9 +1714,10 @@ __device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
 // Persistent, two workgroups per CU (tiles idx = blockIdx.x, + gridDim.x, ...): the next tile's 32 granules per
 // thread are fetched while the four levels of the current one run.
 template <bool INV, bool PRUNE_LAST>
-__global__ void __launch_bounds__(MD_THREADS)
-    k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT, uint32_t ntiles) {
+__device__ __forceinline__ void mid_body(uint32_t *__restrict__ Z, const tile_desc &d, uint32_t mask_hi,
+                                         const uint32_t *__restrict__ MT, uint32_t ntiles, uint32_t *__restrict__ ctr) {
     __shared__ uint32_t lds[256 * TL_ROWS];
+    __shared__ uint32_t s_next;
     constexpr int PER = 256 / MD_WAVES;
     typedef typename tile_regs<PER>::type regs_t;
     const uint32_t lane = threadIdx.x & 63;
@@ -1722,86 +1729,108 @@ __global__ void __launch_bounds__(MD_THREADS)
         for (int i = 0; i < PER; i++) v[i] = g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS];
         return v;
     };
-    // a workgroup takes BOTH row halves of a tile back to back (sequence s: tile pair blockIdx.x + (s / 2) gridDim.x,
-    // half s % 2): the second half finds the tile's masks in L2
-    // (d.rhalves == 1: one tile index per gather tile, the sequence is simply blockIdx.x, + gridDim.x, ...)
+    // a workgroup takes BOTH row halves of a tile back to back: the second half finds the tile's masks in L2
+    // (d.rhalves == 1: one tile index per gather tile).
+    // Which tile pair comes next is drawn from a counter (*ctr, zero at launch), not fixed by blockIdx: of the two
+    // workgroups that share a CU the hardware serves the older one's waves first, so with equal shares one finishes its
+    // list early and the other runs the rest alone, with half the waves the CU needs to overlap its phases
+    // (tools/micro/cu_spread.hip). The first two pairs of a workgroup are fixed (blockIdx.x, + gridDim.x), each further
+    // one is drawn one pair ahead, so the draw's latency never sits in front of a prefetch.
     const uint32_t RH = d.rhalves;
     const uint32_t npairs = ntiles / RH;
     if (blockIdx.x >= npairs) return;
-    const uint32_t nseq = RH * ((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    auto tile_of = [&](uint32_t sq) {
-        return RH == 2 ? 2 * (blockIdx.x + (sq >> 1) * gridDim.x) + (sq & 1) : blockIdx.x + sq * gridDim.x;
-    };
-    uint32_t idx = tile_of(0);
+    uint32_t cur = blockIdx.x, nxt = blockIdx.x + gridDim.x;
     const uint32_t bf = wave;
-    regs_t v = fetch(idx);
+    regs_t v = fetch(RH * cur);
 #pragma unroll 1
-    for (uint32_t sq = 0; sq < nseq; sq++) {
-        idx = tile_of(sq);
-        const uint32_t rh = tile_rh(d, idx);
-        const uint32_t base_w = tile_base(d, tile_no(d, idx));
-        const uint32_t outer = pext32(base_w, mask_hi);
+    while (cur < npairs) {
+        uint32_t drawn = 0;
+        if (threadIdx.x == 0) drawn = 2 * gridDim.x + atomicAdd(ctr, 1u);
+#pragma unroll 1
+        for (uint32_t h = 0; h < RH; h++) {
+            const uint32_t idx = RH * cur + h;
+            const uint32_t rh = tile_rh(d, idx);
+            const uint32_t base_w = tile_base(d, tile_no(d, idx));
+            const uint32_t outer = pext32(base_w, mask_hi);
 #pragma unroll
-        for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
-        __syncthreads();
-        // the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and parked in registers;
-        // during a level they are staged in the wave's own x slots (free while x and y are in registers) and read back as
-        // VGPR operands: no scalar-memory stream whose latency the level would expose
-        // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
-        // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
-        u32x16 mk;
+            for (int i = 0; i < PER; i++) lds[(wave + MD_WAVES * i) * TL_ROWS + lane] = v[i];
+            __syncthreads();
+            // the 1 KiB of masks of each of the four levels, one 16-byte piece per lane, fetched now and parked in registers;
+            // during a level they are staged in the wave's own x slots (free while x and y are in registers) and read back as
+            // VGPR operands: no scalar-memory stream whose latency the level would expose
+            // (one vector value, components picked by constant index: as an array of uint4 it lived in scratch memory, 64 B
+            // written and read back per thread and tile = +50 % HBM writes on this kernel, profiles/r1_v10_pmc.csv)
+            u32x16 mk;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
-            mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
-        }
-        // the prefetch of the next tile comes AFTER the mask loads: vector loads return in order, so waiting for masks
-        // issued behind it would wait for the whole prefetch (vmcnt(0)) before the first level
-        {
-            const uint32_t nidx = tile_of(sq + 1 < nseq ? sq + 1 : sq);
-            v = fetch(nidx);
-        }
-#pragma unroll
-        for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
-            const int b = INV ? 3 - q : q;
-            const bool pruned = PRUNE_LAST && b == 3;
-            const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
-            uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
-            uint32_t *py = px + (16u << b) * TL_ROWS;
-            uint32_t x[16], y[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                x[k] = px[k * TL_ROWS];
-                y[k] = py[k * TL_ROWS];
+            for (int b = 0; b < 4; b++) {
+                const uint4 t = *(const uint4 *)(MT + ((((uint64_t)outer * 4 + b) * 8 + bf) << 8) + lane * 4);
+                mk[4 * b + 0] = t.x, mk[4 * b + 1] = t.y, mk[4 * b + 2] = t.z, mk[4 * b + 3] = t.w;
             }
-            if (INV && !pruned) {
+            // the prefetch of the next tile comes AFTER the mask loads: vector loads return in order, so waiting for masks
+            // issued behind it would wait for the whole prefetch (vmcnt(0)) before the first level
+            {
+                const uint32_t nidx = h + 1 < RH ? idx + 1 : nxt < npairs ? RH * nxt : idx;
+                v = fetch(nidx);
+            }
 #pragma unroll
-                for (int k = 0; k < 16; k++) y[k] ^= x[k];
+            for (int q = 0; q < ((QC_EXP & 16) ? 0 : 4); q++) {
+                const int b = INV ? 3 - q : q;
+                const bool pruned = PRUNE_LAST && b == 3;
+                const uint32_t lvx = ((bf >> b) << (b + 1)) | (bf & ((1u << b) - 1u));
+                uint32_t *px = lds + (lvx << 4) * TL_ROWS + lane;
+                uint32_t *py = px + (16u << b) * TL_ROWS;
+                uint32_t x[16], y[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    x[k] = px[k * TL_ROWS];
+                    y[k] = py[k * TL_ROWS];
+                }
+                if (INV && !pruned) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) y[k] ^= x[k];
+                }
+                {
+                    // x ^= tau (x) y, Karatsuba-style (kara_lds) with 8 x 8 blocks (48 broadcast reads instead of 64) in the forward
+                    // kernel and 4 x 4 blocks (36) in the inverse one: forward with 4 x 4 blocks needs 129 VGPRs, one too many
+                    // for two workgroups per CU (1.50 ms per step instead of 1.17; forcing 128 by attribute: 1.22)
+                    uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
+                    R[lane] = make_uint4(mk[4 * b + 0], mk[4 * b + 1], mk[4 * b + 2], mk[4 * b + 3]);
+                    kara_lds<16, 0, 0, INV ? 4 : 8>(x, y, R);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
+                if (!pruned) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) py[k * TL_ROWS] = INV ? y[k] : y[k] ^ x[k];
+                }
+                if (!(QC_EXP & 64)) __syncthreads();
             }
             {
-                // x ^= tau (x) y, Karatsuba-style (kara_lds) with 8 x 8 blocks (48 broadcast reads instead of 64) in the forward
-                // kernel and 4 x 4 blocks (36) in the inverse one: forward with 4 x 4 blocks needs 129 VGPRs, one too many
-                // for two workgroups per CU (1.50 ms per step instead of 1.17; forcing 128 by attribute: 1.22)
-                uint4 *R = (uint4 *)(lds + (lvx << 4) * TL_ROWS);  // this butterfly's x slots: 4 KiB, owned by this wave
-                R[lane] = make_uint4(mk[4 * b + 0], mk[4 * b + 1], mk[4 * b + 2], mk[4 * b + 3]);
-                kara_lds<16, 0, 0, INV ? 4 : 8>(x, y, R);
+                uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
+#pragma unroll
+                for (int i = 0; i < PER; i++)
+                    g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS] = lds[(wave + MD_WAVES * i) * TL_ROWS + lane];
             }
-#pragma unroll
-            for (int k = 0; k < 16; k++) px[k * TL_ROWS] = x[k];
-            if (!pruned) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) py[k * TL_ROWS] = INV ? y[k] : y[k] ^ x[k];
-            }
-            if (!(QC_EXP & 64)) __syncthreads();
+            if (h == 0 && threadIdx.x == 0) s_next = drawn;
+            __syncthreads();
         }
-        {
-            uint32_t *g = Z + (uint64_t)(base_w | tile_word(d, wave)) * ROWS + rh * TL_ROWS + lane;
-#pragma unroll
-            for (int i = 0; i < PER; i++)
-                g[(uint64_t)tile_word(d, MD_WAVES * i) * ROWS] = lds[(wave + MD_WAVES * i) * TL_ROWS + lane];
-        }
-        __syncthreads();
+        cur = nxt;
+        nxt = __builtin_amdgcn_readfirstlane(s_next);
     }
+}
+// the inverse kernel (4 x 4 Karatsuba blocks) lands at 131-135 VGPRs by itself: held at 128 so that two workgroups share a CU
+// (the same attribute costs the forward kernel 13 %)
+template <bool INV, bool PRUNE_LAST>
+__global__ void __launch_bounds__(MD_THREADS)
+    k_mid(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT, uint32_t ntiles,
+          uint32_t *__restrict__ ctr) {
+    mid_body<INV, PRUNE_LAST>(Z, d, mask_hi, MT, ntiles, ctr);
+}
+template <bool PRUNE_LAST>
+__global__ void __launch_bounds__(MD_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    k_mid_inv(uint32_t *__restrict__ Z, tile_desc d, uint32_t mask_hi, const uint32_t *__restrict__ MT, uint32_t ntiles,
+              uint32_t *__restrict__ ctr) {
+    mid_body<true, PRUNE_LAST>(Z, d, mask_hi, MT, ntiles, ctr);
 }
 
 // MT[((outer * 4 + b) * 8 + bf)][j][k] = all-ones iff output plane k of (twiddle (x) y) takes input plane j
@@ -2341,6 +2370,16 @@ static bool make_taylor(uint32_t R, bool groupA, taylor_desc &t, unsigned &grid,
     return true;
 }
 
+// a zeroed work counter for one launch of a kernel that draws its tiles (k_mid): slots of c->d_ctr are handed out in turn
+// and the array is cleared, in stream order, when all have been used
+static uint32_t *qc_next_counter(sot_ctx *c, uint32_t n = 1) {
+    if (c->ctr_next + n > QC_NCTR) {
+        (void)hipMemsetAsync(c->d_ctr, 0, QC_NCTR * sizeof(uint32_t), c->stream);
+        c->ctr_next = 0;
+    }
+    c->ctr_next += n;
+    return c->d_ctr + c->ctr_next - n;
+}
 static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_elems, bool inverse, bool units_in_top,
                           const move_list *sub_fwd, const move_list *sub_inv) {
     const uint64_t nwords = 1ull << (ell_elems - 5);
@@ -2437,12 +2476,12 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
         if (!units_in_top) whole_units();
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, (k_conv_unit<false, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_fwd, ugrid, nact16);
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<false, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_fwd, ugrid, nact16, qc_next_counter(c, 8));
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, (k_conv_unit<true, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_inv, ugrid, nact16);
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<true, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_inv, ugrid, nact16, qc_next_counter(c, 8));
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) whole_units();
@@ -2687,17 +2726,17 @@ static void fft_forward_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p, int up
     top.zero_bit = 0;  // tile bit 0 = level r = 1 = the upper half of the row
     launch_top(c, KID_FFT_TOP, false, top, Z, p.up_fwd);
     if (upto >= 2)
-        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1), qc_next_counter(c));
     if (upto >= 3) {
-        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
+        SOT_LAUNCH(c, KID_FFT_MID, (k_mid<false, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2), qc_next_counter(c));
         for (auto &d : p.w32) launch_w32(c, KID_FFT_MID, false, d, Z, p.up_none);
     }
 }
 
 static void fft_inverse_upper(sot_ctx *c, uint32_t *Z, const fft_plan &p) {
     for (size_t i = p.w32.size(); i-- > 0;) launch_w32(c, KID_IFFT_MID, true, p.w32[i], Z, p.up_none);
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2));
-    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid<true, false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1));
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid_inv<true>), dim3(mid_grid(c, p.mid2)), dim3(MD_THREADS), Z, p.mid2, p.mid2_hi, c->MT2, tile_grid(p.mid2), qc_next_counter(c));
+    SOT_LAUNCH(c, KID_IFFT_MID, (k_mid_inv<false>), dim3(mid_grid(c, p.mid1)), dim3(MD_THREADS), Z, p.mid1, p.mid1_hi, c->MT1, tile_grid(p.mid1), qc_next_counter(c));
     launch_top(c, KID_IFFT_TOP, true, p.top, Z, p.up_inv);
 }
 
@@ -2792,6 +2831,9 @@ int qc_init(sot_ctx *c) {
     SOT_HIP(hipGetLastError());
     fft_plan *plan = new fft_plan(make_plan(m, c->opts));
     c->qc_plan = plan;
+    SOT_TRY(dev_alloc(c, (void **)&c->d_ctr, QC_NCTR * sizeof(uint32_t)));
+    SOT_HIP(hipMemsetAsync(c->d_ctr, 0, QC_NCTR * sizeof(uint32_t), c->stream));
+    c->ctr_next = 0;
     SOT_TRY(dev_alloc(c, (void **)&c->MT1, 16ull * 4 * 8 * 256 * 4));
     SOT_TRY(dev_alloc(c, (void **)&c->MT2, 256ull * 4 * 8 * 256 * 4));
     hipLaunchKernelGGL(k_build_midmasks, dim3(16 * 4 * 8 * 16 / 256), dim3(256), 0, c->stream, plan->mid1, plan->mid1_hi, 9u,
@@ -2830,7 +2872,7 @@ void qc_set_rows_active(sot_ctx *c, uint32_t rows) {
 void qc_free(sot_ctx *c) {
     delete (fft_plan *)c->qc_plan;
     c->qc_plan = nullptr;
-    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->sbv, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2};
+    void *ptrs[] = {c->Z0, c->Z1, c->Amat, c->sbv, c->a2, c->a_hi, c->TW, c->TWC, c->up_list, c->LM, c->MT1, c->MT2, c->d_ctr};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }

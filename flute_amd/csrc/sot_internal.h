@@ -125,6 +125,7 @@ struct shard_state {
     bool slots_ready = false, enc_slots_ready = false;
 };
 
+#define QC_NCTR 1024
 struct sot_ctx {
     // every sot_* entry point that takes the context holds this lock for the whole call: sender and receiver share the
     // GGM scratch, the Z buffers and one stream, and the reference drives both directions from two threads
@@ -160,6 +161,8 @@ struct sot_ctx {
     uint32_t rows_active = 128;             // bit rows that hold data (qc_set_rows_active)
     uint32_t *TW = nullptr, *TWC = nullptr; // twiddle matrix tables
     uint32_t *LM = nullptr;                 // per value word packed twiddle masks of the intra-word levels [nw/32][5][240] (packed: see d_LOWCMAP)
+    uint32_t *d_ctr = nullptr;               // QC_NCTR zeroed work counters (qc_next_counter)
+    uint32_t ctr_next = 0;
     uint32_t *MT1 = nullptr, *MT2 = nullptr; // twiddle masks of the 16-plane passes (levels 9..12 / 13..16)
     void *qc_plan = nullptr;                // fft_plan (qc.hip): tile descriptors of the passes
     uint32_t *up_list = nullptr;            // move lists of the whole-unit conversion phases
