@@ -606,7 +606,7 @@ __device__ __forceinline__ cu_regs cu_load_tile(const uint32_t *g, uint32_t su, 
 // overlap there is; with RQ = 2 a second workgroup on the CU overlaps its phases with this one's barriers as well).
 template <bool INV, int RQ>
 __global__ void __launch_bounds__(256 * RQ) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t nact, uint32_t *__restrict__ ctr) {
+k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t nact) {
     constexpr uint32_t T = 256 * RQ;      // threads
     constexpr uint32_t SU = 9 * RQ;       // u4 per sub-unit in LDS: 8 words x RQ quads + one word of padding
     constexpr uint32_t LANES = 8 * RQ;    // u4 of a sub-unit = lanes per move in P2
@@ -618,17 +618,14 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
         const uint32_t t = xcd_slice_order(v, nact, ntiles);
         return D + (uint64_t)(t / nact) * 2048 * ROWS + (t & (nact - 1u)) * (4 * RQ);
     };
-    // tiles blockIdx.x and blockIdx.x + gridDim.x, then drawn from *ctr (zero at launch) one tile ahead: see k_mid
-    __shared__ uint32_t s_next;
-    uint32_t t = blockIdx.x, tn = blockIdx.x + gridDim.x;
+    // (a fixed list of tiles per workgroup: drawing them from a counter as k_mid does gains 3 % here and costs 18 % more HBM
+    // traffic -- the slices of a line no longer meet in their XCD's L2 at the same time: profiles/r3_notes.md)
+    uint32_t t = blockIdx.x;
     if (t >= ntiles) return;
     for (uint32_t i = threadIdx.x; i < mv.step_end[mv.nsteps - 1]; i += T) mvl[i] = mv.list[i];
     cu_regs nx = cu_load_tile<INV>(gptr(t), su, quad);
 #pragma unroll 1
-    for (; t < ntiles; t = tn, tn = __builtin_amdgcn_readfirstlane(s_next)) {
-        uint32_t drawn = 0;
-        // (one counter per XCD residue: xcd_slice_order relies on tile v running on XCD v % 8)
-        if (threadIdx.x == 0) drawn = (gridDim.x % 8 ? atomicAdd(ctr, 1u) : atomicAdd(ctr + (blockIdx.x & 7u), 1u) * 8 + (blockIdx.x & 7u)) + 2 * gridDim.x;
+    for (; t < ntiles; t += gridDim.x) {
         uint32_t *g = gptr(t);
         {
             u4 w[8] = {nx.a, nx.b, nx.c, nx.d, nx.e, nx.f, nx.g, nx.h};
@@ -644,7 +641,7 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
         __syncthreads();
         {  // next tile: in flight during the LDS phases (the last iteration re-reads its own tile: unconditional
            // loads keep w[] in registers)
-            nx = cu_load_tile<INV>(gptr(tn < ntiles ? tn : t), su, quad);
+            nx = cu_load_tile<INV>(gptr(t + gridDim.x < ntiles ? t + gridDim.x : t), su, quad);
         }
         // P2 forward comes after P1, inverse before it
         for (int part = 0; part < 2; part++) {
@@ -718,7 +715,6 @@ k_conv_unit(uint32_t *__restrict__ D, move_list mv, uint32_t ntiles, uint32_t na
 #pragma unroll
             for (int j = 0; j < 8; j++) *(u4 *)(g + (uint64_t)(su + 256 * j) * ROWS + 4 * quad) = lds[cu_idx<RQ>(su + 256 * j) + quad];
         }
-        if (threadIdx.x == 0) s_next = drawn;
         __syncthreads();  // the tile's LDS is free again
     }
 }
@@ -2476,12 +2472,12 @@ static int run_conversion(sot_ctx *c, uint32_t *bufs[2], int cur, uint32_t ell_e
         }
         if (!units_in_top) whole_units();
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, (k_conv_unit<false, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_fwd, ugrid, nact16, qc_next_counter(c, 8));
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<false, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_fwd, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 0);
     } else {
         if (fused && tb == 16)
-            SOT_LAUNCH(c, kid_t, (k_conv_unit<true, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_inv, ugrid, nact16, qc_next_counter(c, 8));
+            SOT_LAUNCH(c, kid_t, (k_conv_unit<true, QC_CU_RQ>), dim3(ugrid < ucap ? ugrid : ucap), dim3(256 * QC_CU_RQ), bufs[cur], *sub_inv, ugrid, nact16);
         else if (small.n)
             SOT_LAUNCH(c, kid_t, k_conv_tile<1>, dim3(tgrid), dim3(CT_THREADS), bufs[cur], tb, small, 1);
         if (!units_in_top) whole_units();
