@@ -42,6 +42,8 @@ __global__ void __launch_bounds__(AZ_THREADS)
     constexpr uint32_t KW = SENDER ? 44 : 88, KS = AZ_KSTRIDE(SENDER);
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ __align__(16) uint32_t keys[128 * KS];
+    __shared__ uint32_t s_ctr;
+    if (threadIdx.x == 0) s_ctr = 0;
     aes_lds_fill(te);
     for (uint32_t i = threadIdx.x; i < 128 * KW; i += AZ_THREADS) keys[(i / KW) * KS + i % KW] = rks[i];
     __syncthreads();
@@ -49,7 +51,17 @@ __global__ void __launch_bounds__(AZ_THREADS)
     const uint32_t *ka = keys + lane * KS, *kb = keys + (lane + 64) * KS;
     const uint32_t rbit_a = SENDER ? base_choice[lane] : 0, rbit_b = SENDER ? base_choice[lane + 64] : 0;
     blk_t *Ua = U + (uint64_t)lane * nj, *Ub = U + (uint64_t)(lane + 64) * nj;
-    for (uint64_t j = (uint64_t)blockIdx.x * AZ_TILES + wave; j < nj; j += (uint64_t)gridDim.x * AZ_TILES) {
+    // A wave DRAWS its tiles from the workgroup's share (tile k of workgroup b is column (k / 16) * 16 gridDim + 16 b + k % 16;
+    // k comes from a counter in LDS, the first one is the wave's own index): the CU serves its oldest waves first, so with
+    // equal fixed shares they finish early and the youngest run the tail of the kernel with too few waves beside them to
+    // keep the LDS pipe busy (tools/micro/cu_spread.hip). One counter for the whole grid would serialise 2^17 atomics on
+    // one address (1.5 ms instead of 0.7); between CUs the spread is 1 %.
+    const uint64_t nfix = (uint64_t)gridDim.x * AZ_TILES;
+    auto column = [&](uint32_t k) { return (uint64_t)(k >> 4) * nfix + (uint64_t)blockIdx.x * AZ_TILES + (k & 15u); };
+    uint64_t j = column(wave);
+    for (; j < nj; ) {
+        uint32_t drawn = 0;
+        if (lane == 0) drawn = atomicAdd(&s_ctr, 1u);
         const blk_t ctr = make_uint4((uint32_t)j, (uint32_t)(j >> 32), 0, 0);
         blk_t ta, tb;
         // receiver: rows l and l + 64 one after the other (four chains at once keep four sets of per-lane round keys in
@@ -84,6 +96,7 @@ __global__ void __launch_bounds__(AZ_THREADS)
             if (ia < count) out[ia] = a0;
             if (ib < count) out[ib] = b0;
         }
+        j = column(AZ_TILES + __builtin_amdgcn_readfirstlane(drawn));
     }
 }
 
