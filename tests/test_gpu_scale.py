@@ -201,6 +201,16 @@ def test_odd_sizes_match_oracle(orc, n, T):
     _encode_both_vs_oracle(orc, n, T, n % 9973)
 
 
+def test_random_sizes_match_oracle(orc):
+    """sixteen sizes drawn (seeded) from 2 ... 6 000 000, ten log-uniform and six uniform, with random thread counts: every
+    transform size m = 21 ... 24, ragged last tiles, tile counts that are no multiple of the grids -- both roles, choice
+    words and MT words against the oracle"""
+    rng = np.random.default_rng(20261111)
+    sizes = [int(2 ** rng.uniform(1, 22.5)) for _ in range(10)] + [int(rng.integers(1 << 16, 6000000)) for _ in range(6)]
+    for i, n in enumerate(sizes):
+        _encode_both_vs_oracle(orc, n, int(rng.integers(1, 9)), 7000 + i, receiver=True, hashes=True, unpacked=(i % 3 == 0))
+
+
 @pytest.mark.parametrize("log2n", [23, 24])
 def test_headline_size_matches_oracle(orc, log2n):
     """n = 2^24 is the size bench.py times (transform size m = 25: k_fft_low<1,16> with nb = 9, k_top<.,9>) and n = 2^23
