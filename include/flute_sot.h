@@ -71,7 +71,8 @@ int sot_configure(uint64_t n, uint64_t scaler, uint64_t sec_param, sot_conf *out
 /* Encoder::configure + pprf::{Sender,Receiver}::new + init_a_polynomials
  * (silent_ot/mod.rs:148,331; quasi_cyclic_encode.rs:127-138): allocates every device buffer for one
  * sender and one receiver instance of `n` OTs and transforms the scaler - 1 public polynomials a_s once. A geometry with
- * n_blocks * 128 < P (possible for scaler > 2 at some n; the reference's modp panics on it) is refused with SOT_EINVAL. */
+ * n_blocks * 128 < P (about one n in forty at scaler 2, more at larger scalers: N = N2 / scaler is no multiple of 128 and the
+ * last, partial Block would be needed to hold P bits; the reference's modp panics on it) is refused with SOT_EINVAL. */
 int sot_ctx_create(uint64_t n, uint64_t scaler, int device, sot_ctx **out);
 void sot_ctx_destroy(sot_ctx *ctx);
 int sot_ctx_conf(const sot_ctx *ctx, sot_conf *out);

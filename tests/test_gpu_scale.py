@@ -207,8 +207,20 @@ def test_random_sizes_match_oracle(orc):
     words and MT words against the oracle"""
     rng = np.random.default_rng(20261111)
     sizes = [int(2 ** rng.uniform(1, 22.5)) for _ in range(10)] + [int(rng.integers(1 << 16, 6000000)) for _ in range(6)]
+    import flute_amd as fa
+    refused = 0
     for i, n in enumerate(sizes):
-        _encode_both_vs_oracle(orc, n, int(rng.integers(1, 9)), 7000 + i, receiver=True, hashes=True, unpacked=(i % 3 == 0))
+        T = int(rng.integers(1, 9))
+        conf = orc.configure(n)
+        if int(conf.n_blocks) * 128 < int(conf.P):
+            # about one size in forty: N = N2 / scaler is no multiple of 128 and its last partial Block is needed to hold P
+            # bits -- the reference's modp panics on it (quasi_cyclic_encode.rs:289-303), the library refuses the context
+            with pytest.raises(fa.SotError, match="unsupported geometry"):
+                fa.Engine(n)
+            refused += 1
+            continue
+        _encode_both_vs_oracle(orc, n, T, 7000 + i, receiver=True, hashes=True, unpacked=(i % 3 == 0))
+    assert refused <= 2
 
 
 @pytest.mark.parametrize("log2n", [23, 24])
