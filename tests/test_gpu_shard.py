@@ -139,6 +139,21 @@ def test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated, scaler=2)
     assert np.array_equal(mt, w_mt), "MT words"
 
 
+def test_sharded_expansion_random_shapes(fa, orc):
+    """twelve seeded random (n, threads, ranks, GGM mode, scaler) shapes, n from 2 to 3 000 000: byte-identical to one GPU"""
+    rng = np.random.default_rng(424242)
+    done = 0
+    while done < 12:
+        n = int(2 ** rng.uniform(1, 21.5))
+        T, world = int(rng.integers(1, 9)), int(rng.choice([2, 4, 8]))
+        replicated, scaler = bool(rng.integers(0, 2)), int(rng.choice([2, 2, 2, 3]))
+        conf = orc.configure(n, scaler)
+        if int(conf.n_blocks) * 128 < int(conf.P):
+            continue  # a geometry the reference's modp panics on: refused by sot_ctx_create (test_gpu_scale.py)
+        test_sharded_expansion_equals_one_gpu(fa, n, T, world, replicated, scaler)
+        done += 1
+
+
 def test_sharded_context_refuses_whole_matrix_stages(fa):
     from flute_amd.lib import SotError
     e = fa.ShardedEngine(1000, 1, 2)
