@@ -327,7 +327,7 @@ def alsz_bench(fa, torch, device, log2n, reps):
         "sender": {"aes_blocks_per_s": aes_s, "frac_of_lds_lookup_peak": aes_s / AES_PEAK_PER_S,
                    "hbm_bytes_per_ot": 48.0, "hbm_gb_per_s": 48.0 * count / (ms_s * 1e-3) / 1e9},
         "bound": "lds (AES T-table lookups: 3 blocks per extension per side); the 128 x 128 bit transposes run in the wave's registers",
-        "note": "wall time of one call per side incl. 256 / 128 host key schedules and their upload; one-shot "
+        "note": "wall time of one call per side incl. the upload of the 256 / 128 base-OT keys (expanded to round keys inside the kernel); one-shot "
                 "sot_alsz_send / sot_alsz_receive add device allocation and PCIe copies of the u rows and messages",
     }
 

@@ -36,16 +36,34 @@
 // sixteen waves of the workgroup drift apart and overlap each other's lookup, transpose and store phases.
 template <bool SENDER>
 __global__ void __launch_bounds__(AZ_THREADS)
-    k_alsz(const uint32_t *__restrict__ rks /* SENDER: [128][44], else [128][2][44] */, const blk_t *__restrict__ choices,
+    k_alsz(const uint32_t *__restrict__ seeds /* the base-OT Blocks = AES keys; SENDER: [128][4] words, else [128][2][4] */,
+           const blk_t *__restrict__ choices,
            blk_t delta, const uint8_t *__restrict__ base_choice /* SENDER: [128] 0/1 */, blk_t *__restrict__ U /* [128][nj] */,
            uint64_t nj, uint64_t count, blk_t *__restrict__ out) {
-    constexpr uint32_t KW = SENDER ? 44 : 88, KS = AZ_KSTRIDE(SENDER);
+    constexpr uint32_t KS = AZ_KSTRIDE(SENDER);
     __shared__ uint32_t te[1][AES_LDS_WORDS];
     __shared__ __align__(16) uint32_t keys[128 * KS];
     __shared__ uint32_t s_ctr;
     if (threadIdx.x == 0) s_ctr = 0;
     aes_lds_fill(te);
-    for (uint32_t i = threadIdx.x; i < 128 * KW; i += AZ_THREADS) keys[(i / KW) * KS + i % KW] = rks[i];
+    __syncthreads();
+    // FIPS-197 key expansion of the 128 / 256 base-OT keys, one key per thread, S-box = byte 1 of the table's TE0 replicas
+    // (TE0 = (2S, S, S, 3S)); on the host it was 40 us of every call
+    if (threadIdx.x < 128 * (SENDER ? 1 : 2)) {
+        uint32_t *kk = keys + (SENDER ? threadIdx.x * KS : (threadIdx.x >> 1) * KS + (threadIdx.x & 1u) * 44);
+        const uint4 k4 = *(const uint4 *)(seeds + 4 * threadIdx.x);
+        uint32_t w0 = k4.x, w1 = k4.y, w2 = k4.z, w3 = k4.w, rcon = 1;
+        kk[0] = w0, kk[1] = w1, kk[2] = w2, kk[3] = w3;
+#pragma unroll 1
+        for (int r = 1; r <= 10; r++) {
+            auto S = [&](uint32_t x) { return (te[0][(x & 255u) * 64] >> 8) & 255u; };
+            // SubWord(RotWord(w3)) ^ rcon, bytes little-endian in the word
+            w0 ^= (S(w3 >> 8) | (S(w3 >> 16) << 8) | (S(w3 >> 24) << 16) | (S(w3) << 24)) ^ rcon;
+            w1 ^= w0, w2 ^= w1, w3 ^= w2;
+            kk[4 * r] = w0, kk[4 * r + 1] = w1, kk[4 * r + 2] = w2, kk[4 * r + 3] = w3;
+            rcon = (rcon << 1) ^ ((rcon & 0x80u) ? 0x11bu : 0u);
+        }
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *ka = keys + lane * KS, *kb = keys + (lane + 64) * KS;
@@ -107,12 +125,12 @@ struct sot_alsz_ctx {
     int device;
     uint64_t max_count, max_nj;
     hipStream_t stream;
-    uint32_t *d_rks;  // [256][44]
+    uint32_t *d_rks;  // [256][4]: the base-OT Blocks (expanded to round keys by the kernel)
     blk_t *d_ch;      // [max_nj] padded choice Blocks
     blk_t *d_U;       // [128][nj] Blocks (row stride = nj of the last call)
     blk_t *d_out;     // [max_count] (receiver) / [2 max_count] (sender)
     uint8_t *d_bc;    // [128]
-    uint32_t *h_rks;  // pinned staging of the expanded keys
+    uint32_t *h_rks;  // pinned staging of the base-OT Blocks (+ the 128 base choices behind them)
     uint64_t last_count, last_nj;
     hipEvent_t done;  // recorded behind the last kernel of every call: what a consumer of d_U / d_out on another stream waits for
     std::mutex mu;
@@ -158,12 +176,12 @@ extern "C" int sot_alsz_ctx_create(int device, uint64_t max_count, sot_alsz_ctx 
     a->d_rks = nullptr, a->d_ch = nullptr, a->d_U = nullptr, a->d_out = nullptr, a->d_bc = nullptr, a->h_rks = nullptr;
     const bool ok = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess &&
                     hipEventCreateWithFlags(&a->done, hipEventDisableTiming) == hipSuccess &&
-                    hipMalloc((void **)&a->d_rks, 256 * 44 * 4) == hipSuccess &&
+                    hipMalloc((void **)&a->d_rks, 256 * 16) == hipSuccess &&
                     hipMalloc((void **)&a->d_ch, a->max_nj * 16) == hipSuccess &&
                     hipMalloc((void **)&a->d_U, (size_t)128 * a->max_nj * 16) == hipSuccess &&
                     hipMalloc((void **)&a->d_out, (size_t)a->max_nj * 128 * 32) == hipSuccess &&
                     hipMalloc((void **)&a->d_bc, 128) == hipSuccess &&
-                    hipHostMalloc((void **)&a->h_rks, 256 * 44 * 4 + 128, hipHostMallocDefault) == hipSuccess;
+                    hipHostMalloc((void **)&a->h_rks, 256 * 16 + 128, hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         alsz_free(a);
@@ -209,15 +227,11 @@ static int alsz_check(const sot_alsz_ctx *a, uint64_t count) {
     }
     return SOT_OK;
 }
-// expands the nkeys base-OT seeds into the pinned staging buffer and starts their upload
+// copies the nkeys base-OT Blocks into the pinned staging buffer and starts their upload
 static int alsz_keys(sot_alsz_ctx *a, const void *base_ots, uint32_t nkeys) {
     SOT_HIP(hipStreamSynchronize(a->stream));  // the staging buffer may still feed the previous call's copy
-    for (uint32_t k = 0; k < nkeys; k++) {
-        aes_rk rk;
-        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
-        memcpy(a->h_rks + k * 44, rk.w, 176);
-    }
-    SOT_HIP(hipMemcpyAsync(a->d_rks, a->h_rks, (size_t)nkeys * 176, hipMemcpyHostToDevice, a->stream));
+    memcpy(a->h_rks, base_ots, (size_t)nkeys * 16);
+    SOT_HIP(hipMemcpyAsync(a->d_rks, a->h_rks, (size_t)nkeys * 16, hipMemcpyHostToDevice, a->stream));
     return SOT_OK;
 }
 static inline unsigned alsz_grid(uint64_t nj) {
@@ -265,7 +279,7 @@ extern "C" int sot_alsz_ctx_send(sot_alsz_ctx *a, const void *base_ots, const vo
     SOT_TRY(alsz_keys(a, base_ots, 128));
     blk_t delta;
     memcpy(&delta, base_choices, 16);
-    uint8_t *bc = (uint8_t *)(a->h_rks + 256 * 44);
+    uint8_t *bc = (uint8_t *)(a->h_rks + 256 * 4);
     for (int i = 0; i < 128; i++) bc[i] = (((const uint8_t *)base_choices)[i >> 3] >> (i & 7)) & 1;
     SOT_HIP(hipMemcpyAsync(a->d_bc, bc, 128, hipMemcpyHostToDevice, a->stream));
     const blk_t *U = (const blk_t *)u_dev;
@@ -331,7 +345,7 @@ extern "C" int sot_alsz_send(int device, const void *base_ots, const void *base_
 // array keeps the previous call's contents (the one region that must start at zero, the choice padding, is cleared).
 #define AZ_NA_MAX_COUNT (1ull << 16)                 // OT extensions per call
 #define AZ_NA_NJ (AZ_NA_MAX_COUNT / 128)             // 128-OT tiles
-#define AZ_NA_OFF_RKS 0                              // [256][44] words
+#define AZ_NA_OFF_RKS 0                              // [256][4] words (the region keeps its 45 056 B)
 #define AZ_NA_OFF_CH (AZ_NA_OFF_RKS + 256 * 44 * 4)  // 45056 = 176 * 256: [nj] Blocks
 #define AZ_NA_OFF_U (AZ_NA_OFF_CH + AZ_NA_NJ * 16)   // [128][nj] Blocks
 #define AZ_NA_OFF_OUT (AZ_NA_OFF_U + 128 * AZ_NA_NJ * 16)
@@ -379,13 +393,7 @@ extern "C" int sot_alsz_receive_noalloc(int device, const void *base_ots, const 
     blk_t *const d_U = (blk_t *)(base + AZ_NA_OFF_U);
     blk_t *const d_out = (blk_t *)(base + AZ_NA_OFF_OUT);
     const uint64_t cols = count / 8, nj = (count + 127) / 128;
-    uint32_t rks[256 * 44];  // 44 KiB of stack: no heap allocation on the host either
-    for (uint32_t k = 0; k < 256; k++) {
-        aes_rk rk;
-        aes_expand_key_host((const uint8_t *)base_ots + 16 * k, &rk);
-        memcpy(&rks[k * 44], rk.w, 176);
-    }
-    SOT_HIP(hipMemcpy(d_rks, rks, sizeof(rks), hipMemcpyHostToDevice));
+    SOT_HIP(hipMemcpy(d_rks, base_ots, 256 * 16, hipMemcpyHostToDevice));  // expanded to round keys by the kernel
     // choices as nj whole Blocks: the bytes past count / 8 must be zero, whatever the last call left there
     SOT_HIP(hipMemset(d_ch, 0, nj * 16));
     SOT_HIP(hipMemcpy(d_ch, choice_bytes, cols, hipMemcpyHostToDevice));
