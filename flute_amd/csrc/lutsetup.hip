@@ -529,10 +529,12 @@ __global__ void __launch_bounds__(256)
 //      from LDS instead of 2^p - 1 bits from HBM;
 //   3. per (instance, gate): the table permuted by m, its zeta transform Z, parity(Z & L) ^ lambda_out.
 // cpos[g][s]: compact bit position of lsrc[g][s]; gcls[g] = class | rank << 16 | min(count, 8) << 24 (rank 255: no words).
-__device__ __forceinline__ uint32_t bits32_at(const uint64_t *__restrict__ w, uint64_t bit) {
+// bits [bit, bit + need) of the store, need <= 32 (the following word is only touched when those bits reach into it: the last
+// segment of the last instance ends with the allocation)
+__device__ __forceinline__ uint32_t bits32_at(const uint64_t *__restrict__ w, uint64_t bit, uint32_t need) {
     const uint32_t sh = (uint32_t)(bit & 63);
     uint64_t v = w[bit >> 6] >> sh;
-    if (sh > 32) v |= w[(bit >> 6) + 1] << (64 - sh);
+    if (sh + need > 64) v |= w[(bit >> 6) + 1] << (64 - sh);
     return (uint32_t)v;
 }
 __global__ void __launch_bounds__(256)
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t c = cw - woff[sg], len = (sg == 0 ? n_in : tcount[sg - 1]) - 32 * c;
         const uint64_t inst = (uint64_t)inst0 + i0 + il;
         const uint64_t bit = (sg == 0 ? inst * n_in : lbase[sg - 1] + inst * tcount[sg - 1]) + 32 * c;
-        uint32_t v = bits32_at(vals, bit);
+        uint32_t v = bits32_at(vals, bit, len < 32 ? len : 32u);
         if (len < 32) v &= (1u << len) - 1u;
         comp[it] = v;
     }
