@@ -288,7 +288,7 @@ int sot_alsz_send(int device, const void *base_ots, const void *base_choices, co
                   void *msgs_out);
 
 /* Device-resident OT-extension context: one zappot::ot_ext::Sender or Receiver instance (ot_ext/mod.rs:28-46, :144-154)
- * whose device buffers (expanded keys, choices, the 128 x count u-row matrix, the hashed messages) are allocated once,
+ * whose device buffers (base-OT keys, choices, the 128 x count u-row matrix, the hashed messages) are allocated once,
  * for up to max_count extensions per call. The one-shot sot_alsz_receive / sot_alsz_send above are this context created
  * and destroyed around a single call. Calls on one context are serialised by a lock; they run on the context's own
  * (non-blocking) stream. ORDERING of device-resident hand-offs: sot_alsz_ctx_send given the sot_alsz_ctx_u_dev pointer
@@ -318,7 +318,7 @@ int sot_alsz_ctx_sync(sot_alsz_ctx *actx);
 /* The one entry point that allocates nothing. NO counterpart in the reference: it exists for callers that cannot call
  * hipMalloc -- tight serving loops, harnesses that forbid allocation. It is synchronous on the null stream (blocking
  * copies), so it is not for use inside a HIP stream capture. Same arguments,
- * computation and results as sot_alsz_receive, but the device buffers (expanded keys, padded choices, u-row matrix,
+ * computation and results as sot_alsz_receive, but the device buffers (base-OT keys, padded choices, u-row matrix,
  * hashed messages) are one file-scope device array of 2 150 400 bytes per GPU, held until the process ends; the call
  * makes no hipMalloc / hipFree and no host heap allocation. count <= sot_alsz_noalloc_max_count() = 65 536 OTs per call,
  * larger counts return SOT_EINVAL. Every call on a GPU shares that GPU's array (the last call's contents are
